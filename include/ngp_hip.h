@@ -1,0 +1,247 @@
+/*
+ * ngp_hip.h -- C ABI of libngp_hip.so, the MI355X (gfx950) implementation of the
+ * Instant-NGP render path of sisl/NeRFSafetyValidation.
+ *
+ * This is the drop-in boundary: one entry point per function of the reference's
+ * four pybind11 extension modules (the only native interface its Python operator
+ * layer calls), plus the fused MI355X-native render entry points that sit behind
+ * nerf/renderer.py::NeRFRenderer.run_cuda.
+ *
+ *   reference interface replaced                          (file:line under /root/reference)
+ *   _raymarching   raymarching/src/raymarching.h:7-18,    raymarching/src/bindings.cpp:5-18
+ *   _gridencoder   gridencoder/src/gridencoder.h:12-13,   gridencoder/src/bindings.cpp:5-8
+ *   _shencoder     shencoder/src/shencoder.h:10-13,       shencoder/src/bindings.cpp:5-8
+ *   _ffmlp         ffmlp/src/ffmlp.h:8-15,                ffmlp/src/bindings.cpp:5-11
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the caller owns every buffer; nothing is allocated on the data path
+ *     (scratch comes in through an explicit workspace argument);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream) and the call returns without synchronising, unless stated;
+ *   - return value: 0 on success, a negative NGP_E* code otherwise;
+ *     ngp_last_error() returns a thread-local description of the last failure.
+ *     The reference raises c10::Error / std::runtime_error at the same places
+ *     (gridencoder.cu:355,372,424-440; ffmlp.cu:636-658); the ctypes shim turns
+ *     a non-zero return into RuntimeError;
+ *   - dtype arguments: NGP_F32 or NGP_F16 (IEEE binary16).
+ *   - argument ORDER follows the reference's native signatures, not the Python
+ *     wrappers' (they differ: SURVEY.md section 8b).
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_OK 0
+#define NGP_EINVAL (-1)    /* unsupported size / dtype / null pointer            */
+#define NGP_ELAUNCH (-2)   /* hipGetLastError() after a launch                    */
+#define NGP_EWORKSPACE (-3)/* workspace too small                                 */
+#define NGP_ENODEVICE (-4) /* no HIP device                                       */
+
+#define NGP_F32 0
+#define NGP_F16 1
+
+typedef void* ngp_stream_t;
+
+#if defined(NGP_BUILD)
+#define NGP_API __attribute__((visibility("default")))
+#else
+#define NGP_API
+#endif
+
+NGP_API const char* ngp_last_error(void);
+NGP_API int ngp_version(void);
+/* number of HIP devices visible (does not create a context on this image) */
+NGP_API int ngp_device_count(void);
+
+/* ---------------- _raymarching (raymarching/src/raymarching.h:7-18) ---------------- */
+
+/* raymarching.cu:150-158 near_far_from_aabb */
+NGP_API int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                           float* nears, float* fars, ngp_stream_t stream);
+/* raymarching.cu:203-211 sph_from_ray */
+NGP_API int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                     ngp_stream_t stream);
+/* raymarching.cu:231-234 / 259-262 */
+NGP_API int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, ngp_stream_t stream);
+NGP_API int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, ngp_stream_t stream);
+/* raymarching.cu:294-302 packbits; N = number of output BYTES */
+NGP_API int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream);
+
+/* raymarching.cu:486-495 march_rays_train.  Slots are handed out by an exclusive
+ * prefix sum in ray order (deterministic member of the reference's atomicAdd
+ * permutation set).  counter[0] += total samples, counter[1] += N, as the
+ * reference's atomics leave them.  workspace: ngp_march_rays_train_workspace(N) bytes. */
+NGP_API size_t ngp_march_rays_train_workspace(uint32_t N);
+NGP_API int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                         const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                         uint32_t perturb, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* raymarching.cu:585-593 / 691-699 */
+NGP_API int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                     uint32_t M, uint32_t N, float* weights_sum, float* depth, float* image,
+                                     ngp_stream_t stream);
+NGP_API int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                      const float* rgbs, const float* deltas, const int32_t* rays,
+                                      const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                      float* grad_sigmas, float* grad_rgbs, ngp_stream_t stream);
+/* raymarching.cu:817-825 march_rays.  The kernel itself zero-fills the unused tail of
+ * every ray's n_step slots and rows [n_alive*n_step, M_padded) so the caller may pass
+ * uninitialised buffers of M_padded rows (the reference wrapper passes torch.zeros). */
+NGP_API int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                   uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                   float* dirs, float* deltas, uint32_t perturb, uint32_t M_padded, ngp_stream_t stream);
+/* raymarching.cu:916-922 composite_rays (updates rays_alive, rays_t, weights_sum, depth, image in place) */
+NGP_API int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                       const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
+                       ngp_stream_t stream);
+
+/* ---------------- _gridencoder (gridencoder/src/gridencoder.h:12-13) ---------------- */
+
+/* gridencoder.cu:415-446.  inputs f32 [B,D]; embeddings [sO,C] dtype; offsets_host: the
+ * SAME int32[L+1] table as the device `offsets` tensor, in host memory (the level
+ * geometry is evaluated on the host once per call); outputs [L,B,C] dtype;
+ * dy_dx [B,L*D*C] dtype or NULL.  D in {2,3}, C in {1,2,4,8}. */
+NGP_API int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                            int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                            ngp_stream_t stream);
+/* gridencoder.cu:448-478.  grad [L,B,C]; grad_embeddings [sO,C] (accumulated into, caller zero-fills);
+ * grad_inputs [B,D] dtype or NULL. */
+NGP_API int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
+                             const int32_t* offsets_host, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                             uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
+                             void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream);
+
+/* ---------------- _shencoder (shencoder/src/shencoder.h:10-13) ---------------- */
+
+/* shencoder.cu:402-420.  inputs f32 [B,3]; outputs f32 [B,C*C]; dy_dx f32 [B,3*C*C] or NULL; C = degree 1..8 */
+NGP_API int ngp_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C,
+                          int calc_grad_inputs, float* dy_dx, ngp_stream_t stream);
+/* shencoder.cu:422-441.  grad_inputs f32 [B,3] is ACCUMULATED into (caller zero-fills). */
+NGP_API int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                           const float* dy_dx, float* grad_inputs, ngp_stream_t stream);
+
+/* ---------------- _ffmlp (ffmlp/src/ffmlp.h:8-15) ---------------- */
+
+/* ffmlp.cu:636-709.  fp16 only.  inputs [B,input_dim], B % 16 == 0 (the wrapper pads to 128);
+ * weights: flat blob [hidden x in | (num_layers-1) x hidden x hidden | output_dim x hidden];
+ * forward_buffer [num_layers,B,hidden] (training) ; outputs [B,output_dim], output_dim == 16.
+ * hidden_dim in {16,32,64,128,256}; input_dim % 16 == 0; activation codes as ffmlp/ffmlp.py:89-96. */
+NGP_API int ngp_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
+                      uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                      uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs, ngp_stream_t stream);
+NGP_API int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
+                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                        uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
+                        ngp_stream_t stream);
+/* ffmlp.cu:711-895 (fused backward + per-layer weight gradients; no CUTLASS, no side streams).
+ * backward_buffer [num_layers,B,hidden]; grad_weights (same shape as weights) is overwritten. */
+NGP_API int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
+                       const uint16_t* forward_buffer, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                       uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                       int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
+                       uint16_t* grad_weights, ngp_stream_t stream);
+/* ffmlp.cu:721-760: the reference allocates CUTLASS split-K streams here; kept as no-ops. */
+NGP_API int ngp_ffmlp_allocate_splitk(size_t n);
+NGP_API int ngp_ffmlp_free_splitk(void);
+
+/* ---------------- nerf/utils.py:52-116 get_rays (full frame, N <= 0 branch) ---------------- */
+
+/* poses [Bc,4,4] f32 cam2world (device); rays_o/rays_d [Bc,H*W,3] f32.  Pixel centres +0.5,
+ * dirs normalised then rotated, origin broadcast.  `pixel_inds` (int32 [n_pix] or NULL)
+ * selects a pixel subset per camera (the Estimator's <=1024-pixel batches);
+ * n_pix is H*W when pixel_inds is NULL. */
+NGP_API int ngp_get_rays(const float* poses, uint32_t Bc, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                 const int32_t* pixel_inds, uint32_t n_pix, float* rays_o, float* rays_d, ngp_stream_t stream);
+
+/* ---------------- fused render path behind NeRFRenderer.run_cuda (renderer.py:329-378) ---------------- */
+
+/* Everything the eval-mode branch of run_cuda does between near_far_from_aabb and the
+ * background mix, with the reference's exact per-iteration schedule
+ * (n_step = clamp(N // n_alive, 1, 8), step += n_step while step < max_steps), executed
+ * without a host round trip per iteration.
+ *
+ * Model description (device pointers, fp16 weights in the FFMLP blob layout):
+ *   sigma net : 32 -> 64 x (1 + sigma_hidden_mm) -> 16   (ReLU, no output activation)
+ *   colour net: 32 -> 64 x (1 + color_hidden_mm) -> 16   (first 3 outputs, sigmoid)
+ *   colour input = [SH degree-4 (16) | geo_feat (15) | 0]  (nerf/network_ff.py:63-70);
+ *   nerf/network.py's nn.Linear backbone is passed zero-padded to these shapes.
+ */
+typedef struct ngp_model {
+    const uint16_t* embeddings;   /* [sO,2] fp16 hash table                               */
+    const int32_t* offsets_host;  /* int32[L+1], host memory                              */
+    uint32_t L;                   /* must be 16                                           */
+    float S;                      /* log2(per_level_scale)                                */
+    uint32_t H_base;              /* base resolution                                      */
+    uint32_t gridtype;            /* 0 hash, 1 tiled                                      */
+    int align_corners;
+    const uint16_t* sigma_weights;/* blob: [64x32 | sigma_hidden_mm x 64x64 | 16x64]      */
+    uint32_t sigma_hidden_mm;     /* 0..2                                                 */
+    const uint16_t* color_weights;/* blob: [64x32 | color_hidden_mm x 64x64 | 16x64]      */
+    uint32_t color_hidden_mm;     /* 0..3                                                 */
+    float bound;                  /* scene bound; encoder input = (x+bound)/(2 bound)     */
+    float density_scale;
+    const uint8_t* density_bitfield; /* [C*H^3/8]                                         */
+    uint32_t cascade;             /* C                                                    */
+    uint32_t grid_size;           /* H (128)                                              */
+} ngp_model;
+
+typedef struct ngp_render_stats {
+    uint64_t samples_marched;     /* non-padding samples generated (sum over iterations)  */
+    uint64_t samples_slots;       /* sum of n_alive*n_step, the reference's batch sizes   */
+    uint32_t iterations;          /* python-loop iterations the reference would have run  */
+    uint32_t rays;                /* N                                                    */
+    uint32_t last_n_alive;        /* n_alive and n_step of the last iteration             */
+    uint32_t last_n_step;
+    uint32_t launches;            /* kernel launches enqueued (incl. run-ahead no-ops)    */
+    uint32_t reserved;
+} ngp_render_stats;
+
+typedef struct ngp_render_ctx ngp_render_ctx;  /* pinned status ring, events, scratch sizes */
+
+/* creates the per-stream context for frames of at most max_rays rays (allocates device scratch
+ * once: this is setup, not the data path) */
+NGP_API int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out);
+NGP_API int ngp_render_ctx_destroy(ngp_render_ctx* ctx);
+
+/* rays_o/rays_d [N,3] f32, nears/fars [N] f32 (from ngp_near_far_from_aabb).
+ * Outputs weights_sum [N], depth [N], image [N,3] f32: the accumulated values BEFORE the
+ * background mix / depth normalisation of renderer.py:375-378 (done by the caller as in the
+ * reference).
+ * last_sigmas [N+128] / last_rgbs [N+128,3] (both or neither; may be NULL): the `sigmas` (already
+ * multiplied by density_scale) and `rgbs` tensors of the reference's LAST loop iteration
+ * (renderer.py:383-384), slot-major n*n_step+k; padding slots hold pad_value[0] (sigma) and
+ * pad_value[1..3] (rgb) -- what the network returns for the zero-filled padding rows.
+ * stats_host may be NULL.  Synchronises `stream` before returning iff stats_host != NULL or sync != 0. */
+NGP_API int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* rays_o, const float* rays_d,
+                    const float* nears, const float* fars, uint32_t N, float dt_gamma, uint32_t max_steps,
+                    uint32_t perturb, float* weights_sum, float* depth, float* image, float* last_sigmas,
+                    float* last_rgbs, const float* pad_value_host, ngp_render_stats* stats_host, int sync,
+                    ngp_stream_t stream);
+
+/* fused hash-grid encode + MLPs on an explicit point list: the body of NeRFNetwork.forward
+ * (nerf/network_ff.py:51-75).  xyzs [M,3] in [-bound,bound], dirs [M,3]; sigmas [M] f32 (already
+ * multiplied by nothing: raw trunc_exp output), rgbs [M,3] f32 (fp16-rounded sigmoid). M % 16 == 0 not required. */
+NGP_API int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas,
+                        float* rgbs, ngp_stream_t stream);
+
+/* ---------------- per-kernel device timing (bench.py roofline leg) ---------------- */
+/* When enabled, selected kernels are bracketed by hipEvents on their own stream.
+ * ngp_prof_read synchronises the recorded events and returns accumulated milliseconds
+ * and launch count for `name`; returns NGP_EINVAL for unknown names. */
+NGP_API int ngp_prof_enable(int on);
+NGP_API int ngp_prof_reset(void);
+NGP_API int ngp_prof_read(const char* name, double* total_ms, uint64_t* launches, double* units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

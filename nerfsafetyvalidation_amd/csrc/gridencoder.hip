@@ -1,0 +1,353 @@
+// gridencoder.hip -- multiresolution hash / tiled grid encoding for gfx950.
+// References are to /root/reference/gridencoder/src/gridencoder.cu.
+//
+// Data layout (unchanged from the reference so the operator stays drop-in):
+//   inputs  f32 [B, D] in [0,1];  embeddings T [sum_l hashmap_size_l, C];  outputs T [L, B, C].
+//
+// Launch geometry: one lane per (point, level), 256-lane workgroups.  The block index is
+// decoded XCD-first: hardware deals consecutive workgroups round-robin over the 8 XCDs,
+// so `blockIdx.x & 7` labels the XCD group.  Each group owns a fixed pair of levels
+// (l, 15-l for L = 16: one cheap dense level + one 2 MiB hashed level), so a level's
+// table slice is only ever touched through ONE 4 MiB L2 and stays resident there.  The
+// mapping affects speed only, never results.
+//
+// Level geometry (scale, resolution; :126-128) is evaluated once per call on the host and
+// handed to the kernel by value.
+#include <hip/hip_fp16.h>
+#include <math.h>
+
+#include "ngp_common.hpp"
+
+namespace ngp {
+
+constexpr int kMaxLevels = 32;
+constexpr int kGridBlock = 256;
+
+struct GridLevels {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+    uint32_t offset[kMaxLevels + 1];
+};
+
+template <typename T, int C>
+struct alignas(sizeof(T) * C) Vec {
+    T v[C];
+};
+
+// :35-51
+template <int D>
+__device__ __forceinline__ uint32_t fast_hash(const uint32_t (&p)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) r ^= p[i] * primes[i];
+    return r;
+}
+
+// :54-72 (entry index, i.e. without the `* C + ch`)
+template <int D>
+__device__ __forceinline__ uint32_t grid_entry(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
+                                               const uint32_t (&p)[D]) {
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += p[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(p);
+    return index % hashmap_size;
+}
+
+// acc += w * g with the reference's scalar_t semantics (see oracle/ngp_oracle.c acc_mul):
+// f32: one fma; f16: product rounded to half, then a half add.
+__device__ __forceinline__ void acc_mul(float& acc, float w, float g) { acc = fmaf(w, g, acc); }
+__device__ __forceinline__ void acc_mul(_Float16& acc, float w, _Float16 g) { acc = acc + (_Float16)(w * (float)g); }
+
+// XCD-aware decode of the 1-D grid: returns false when this block has no work.
+__device__ __forceinline__ bool decode_block(uint32_t L, uint32_t& level, uint32_t& point_block) {
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u, k = bid >> 3;
+    const uint32_t LP = (L + 7u) >> 3;
+    const uint32_t j = k % LP;
+    point_block = k / LP;
+    level = (j & 1u) ? j * 8u + (7u - xcd) : j * 8u + xcd;
+    return level < L;
+}
+
+// :75-224
+template <typename T, int D, int C, bool GRAD>
+__global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                             T* __restrict__ outputs, uint32_t B, uint32_t L, GridLevels lv,
+                                                             T* __restrict__ dy_dx, uint32_t gridtype, bool align_corners) {
+    uint32_t level, pb;
+    if (!decode_block(L, level, pb)) return;
+    const uint32_t b = pb * kGridBlock + threadIdx.x;
+    if (b >= B) return;
+
+    const T* tab = grid + (size_t)lv.offset[level] * C;
+    const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+
+    float in[D];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        oob |= (in[d] < 0 || in[d] > 1);
+    }
+    using V = Vec<T, C>;
+    V* out = reinterpret_cast<V*>(outputs + ((size_t)level * B + b) * C);
+    T* dydx = GRAD ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : nullptr;
+    if (oob) {
+        V z;
+#pragma unroll
+        for (int c = 0; c < C; c++) z.v[c] = (T)0;
+        *out = z;
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < D * C; i++) dydx[i] = (T)0;
+        }
+        return;
+    }
+
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        pos[d] = fmaf(in[d], scale, align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+
+    // gather the 2^D corners (all loads issued before any use)
+    V corner[1 << D];
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        uint32_t pl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
+        const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+        corner[idx] = *reinterpret_cast<const V*>(tab + (size_t)e * C);
+    }
+
+    V res;
+#pragma unroll
+    for (int c = 0; c < C; c++) res.v[c] = (T)0;
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float w = 1;
+#pragma unroll
+        for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc_mul(res.v[c], w, corner[idx].v[c]);
+    }
+    *out = res;
+
+    if (GRAD) {  // :177-222
+#pragma unroll
+        for (int gd = 0; gd < D; gd++) {
+            T rg[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) rg[c] = (T)0;
+#pragma unroll
+            for (int idx = 0; idx < (1 << (D - 1)); idx++) {
+                float w = scale;
+                int left = 0;
+#pragma unroll
+                for (int nd = 0; nd < D - 1; nd++) {
+                    const int d = (nd >= gd) ? (nd + 1) : nd;
+                    const int bit = (idx >> nd) & 1;
+                    w *= bit ? pos[d] : 1 - pos[d];
+                    left |= bit << d;
+                }
+                const int right = left | (1 << gd);
+#pragma unroll
+                for (int c = 0; c < C; c++) acc_mul(rg[c], w, (T)(corner[right].v[c] - corner[left].v[c]));
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) dydx[gd * C + c] = rg[c];
+        }
+    }
+}
+
+// :227-314 scatter of w * grad into the table gradient (float atomics; packed-half atomics for f16).
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                              T* __restrict__ grad_grid, uint32_t B, uint32_t L, GridLevels lv,
+                                                              uint32_t gridtype, bool align_corners) {
+    uint32_t level, pb;
+    if (!decode_block(L, level, pb)) return;
+    const uint32_t b = pb * kGridBlock + threadIdx.x;
+    if (b >= B) return;
+    T* tab = grad_grid + (size_t)lv.offset[level] * C;
+    const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const float x = inputs[(size_t)b * D + d];
+        if (x < 0 || x > 1) return;
+        pos[d] = fmaf(x, scale, align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+    using V = Vec<T, C>;
+    const V g = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float w = 1;
+        uint32_t pl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+            pl[d] = pg[d] + ((idx >> d) & 1);
+        }
+        const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int c = 0; c < C; c++) atomicAdd(reinterpret_cast<float*>(tab) + (size_t)e * C + c, w * (float)g.v[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c += 2) {
+                __half2 v = __halves2half2(__float2half_rn(w * (float)g.v[c]), __float2half_rn(w * (float)g.v[c + 1]));
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(reinterpret_cast<__half*>(tab) + (size_t)e * C + c), v);
+            }
+        }
+    }
+}
+
+// :317-343
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kGridBlock) k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx,
+                                                                    T* __restrict__ grad_inputs, uint32_t B, uint32_t L) {
+    const uint32_t t = blockIdx.x * kGridBlock + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T* dd = dy_dx + (size_t)b * L * D * C;
+    T result = (T)0;
+    for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const T g = grad[((size_t)l * B + b) * C + c];
+            const T x = dd[(size_t)l * D * C + d * C + c];
+            if constexpr (sizeof(T) == 4) result = fmaf((float)g, (float)x, (float)result);
+            else result = result + (T)(g * x);
+        }
+    }
+    grad_inputs[t] = result;
+}
+
+static int fill_levels(GridLevels& lv, const int32_t* offsets_host, uint32_t L, float S, uint32_t H) {
+    for (uint32_t l = 0; l < L; l++) {
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;  // :126
+        lv.scale[l] = scale;
+        lv.resolution[l] = (uint32_t)ceilf(scale) + 1;              // :127
+        lv.offset[l] = (uint32_t)offsets_host[l];
+    }
+    lv.offset[L] = (uint32_t)offsets_host[L];
+    return 0;
+}
+
+template <typename T, int D, int C>
+static void launch_forward(const float* inputs, const void* emb, void* out, uint32_t B, uint32_t L, const GridLevels& lv, bool grad,
+                           void* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+    const uint32_t nb = div_up(B, kGridBlock);
+    const uint32_t LP = (L + 7) / 8;
+    const uint32_t nblocks = nb * LP * 8;
+    if (grad)
+        k_grid_forward<T, D, C, true><<<nblocks, kGridBlock, 0, s>>>(inputs, (const T*)emb, (T*)out, B, L, lv, (T*)dy_dx, gridtype, ac);
+    else
+        k_grid_forward<T, D, C, false><<<nblocks, kGridBlock, 0, s>>>(inputs, (const T*)emb, (T*)out, B, L, lv, nullptr, gridtype, ac);
+}
+
+template <typename T, int D, int C>
+static void launch_backward(const void* grad, const float* inputs, void* grad_emb, uint32_t B, uint32_t L, const GridLevels& lv, bool gi,
+                            const void* dy_dx, void* grad_inputs, uint32_t gridtype, bool ac, hipStream_t s) {
+    const uint32_t nb = div_up(B, kGridBlock);
+    const uint32_t LP = (L + 7) / 8;
+    k_grid_backward<T, D, C><<<nb * LP * 8, kGridBlock, 0, s>>>((const T*)grad, inputs, (T*)grad_emb, B, L, lv, gridtype, ac);
+    if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
+}
+
+#define NGP_DISPATCH_DC(FN, T, ...)                                              \
+    switch (D * 16 + C) {                                                       \
+        case 2 * 16 + 1: FN<T, 2, 1>(__VA_ARGS__); break;                        \
+        case 2 * 16 + 2: FN<T, 2, 2>(__VA_ARGS__); break;                        \
+        case 2 * 16 + 4: FN<T, 2, 4>(__VA_ARGS__); break;                        \
+        case 2 * 16 + 8: FN<T, 2, 8>(__VA_ARGS__); break;                        \
+        case 3 * 16 + 1: FN<T, 3, 1>(__VA_ARGS__); break;                        \
+        case 3 * 16 + 2: FN<T, 3, 2>(__VA_ARGS__); break;                        \
+        case 3 * 16 + 4: FN<T, 3, 4>(__VA_ARGS__); break;                        \
+        case 3 * 16 + 8: FN<T, 3, 8>(__VA_ARGS__); break;                        \
+        default: break;                                                         \
+    }
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs, uint32_t B,
+                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
+                            uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream) {
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
+    NGP_REQUIRE(D == 2 || D == 3, "GridEncoding: D must be 2 or 3 on this build (got %u)", D);
+    NGP_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, "GridEncoding: C must be 1, 2, 4, or 8.");
+    NGP_REQUIRE(L >= 1 && L <= (uint32_t)kMaxLevels, "GridEncoding: L must be in [1, %d]", kMaxLevels);
+    NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_forward: dtype must be NGP_F32 or NGP_F16");
+    NGP_REQUIRE(!calc_grad_inputs || dy_dx, "grid_encode_forward: dy_dx is NULL but calc_grad_inputs is set");
+    GridLevels lv;
+    fill_levels(lv, offsets_host, L, S, H);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("grid_encode_forward", s, B);
+    const bool g = calc_grad_inputs != 0, ac = align_corners != 0;
+    if (dtype == NGP_F32) {
+        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, s)
+    } else {
+        NGP_DISPATCH_DC(launch_forward, _Float16, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, s)
+    }
+    return check_launch("grid_encode_forward");
+}
+
+int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets_host,
+                             void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int dtype,
+                             ngp_stream_t stream) {
+    (void)embeddings;
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(grad && inputs && offsets_host && grad_embeddings, "grid_encode_backward: null pointer");
+    NGP_REQUIRE(D == 2 || D == 3, "GridEncoding: D must be 2 or 3 on this build (got %u)", D);
+    NGP_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, "GridEncoding: C must be 1, 2, 4, or 8.");
+    NGP_REQUIRE(L >= 1 && L <= (uint32_t)kMaxLevels, "GridEncoding: L must be in [1, %d]", kMaxLevels);
+    NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_backward: dtype must be NGP_F32 or NGP_F16");
+    NGP_REQUIRE(!(dtype == NGP_F16 && C == 1), "grid_encode_backward: fp16 with C == 1 is unsupported (grid.py:38 forces fp32 for odd C)");
+    NGP_REQUIRE(!calc_grad_inputs || (dy_dx && grad_inputs), "grid_encode_backward: dy_dx/grad_inputs NULL but calc_grad_inputs set");
+    GridLevels lv;
+    fill_levels(lv, offsets_host, L, S, H);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("grid_encode_backward", s, B);
+    const bool gi = calc_grad_inputs != 0, ac = align_corners != 0;
+    if (dtype == NGP_F32) {
+        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s)
+    } else {
+        switch (D * 16 + C) {
+            case 2 * 16 + 2: launch_backward<_Float16, 2, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
+            case 2 * 16 + 4: launch_backward<_Float16, 2, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
+            case 2 * 16 + 8: launch_backward<_Float16, 2, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
+            case 3 * 16 + 2: launch_backward<_Float16, 3, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
+            case 3 * 16 + 4: launch_backward<_Float16, 3, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
+            case 3 * 16 + 8: launch_backward<_Float16, 3, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
+            default: break;
+        }
+    }
+    return check_launch("grid_encode_backward");
+}
+
+}  // extern "C"

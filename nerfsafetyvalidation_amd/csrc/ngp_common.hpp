@@ -1,0 +1,161 @@
+// Shared host/device helpers of libngp_hip (gfx950 only).
+//
+// Numerics contract (DESIGN.md "Numerics"): every translation unit is compiled with
+// -ffp-contract=off; the fused multiply-adds nvcc's default -fmad=true would form in the
+// reference's expressions are written explicitly as fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/ngp_hip.h"
+
+namespace ngp {
+
+// ---- error plumbing -------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define NGP_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ngp::set_error(__VA_ARGS__);       \
+            return NGP_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+// ---- optional per-kernel timing (ngp_prof_*) -----------------------------------
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t s, double units);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
+static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers ---------------------------------------------------------------
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+__device__ __forceinline__ float signf(float x) { return copysignf(1.0f, x); }
+
+// raymarching.cu:58-83
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t morton3D_invert(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// PCG32 (raymarching/src/pcg32.h:44-170), seeded on the host, advanced per ray on device.
+struct Pcg32 {
+    uint64_t state, inc;
+    __host__ __device__ uint32_t next_uint() {
+        const uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = (uint32_t)(old >> 59u);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+    }
+    __host__ __device__ void seed(uint64_t initstate, uint64_t initseq = 1) {
+        state = 0u;
+        inc = (initseq << 1u) | 1u;
+        next_uint();
+        state += initstate;
+        next_uint();
+    }
+    __host__ __device__ float next_float() {
+        union { uint32_t u; float f; } x;
+        x.u = (next_uint() >> 9) | 0x3f800000u;
+        return x.f - 1.0f;
+    }
+    __host__ __device__ void advance(int64_t delta_) {
+        uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+        uint64_t delta = (uint64_t)delta_;
+        while (delta > 0) {
+            if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+            cur_plus = (cur_mult + 1) * cur_plus;
+            cur_mult *= cur_mult;
+            delta /= 2;
+        }
+        state = acc_mult * state + acc_plus;
+    }
+};
+
+// ---- the occupancy-grid DDA shared by march_rays_train / march_rays / the fused renderer.
+// Follows raymarching.cu:357-404 (identical text at :431-483 and :757-813).
+struct Dda {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bound, dt_gamma, dt_min, dt_max, rH, H3f, Cf, Hf, Hm1;
+    double Hd;
+    const uint8_t* grid;
+
+    __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
+                                         uint32_t max_steps, uint32_t C, uint32_t H) {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        rdx = 1 / dx; rdy = 1 / dy; rdz = 1 / dz;
+        rH = 1 / (float)H;
+        H3f = (float)(H * H * H);
+        bound = bound_; dt_gamma = dt_gamma_;
+        const float SQRT3 = 1.7320508075688772f;
+        dt_min = 2 * SQRT3 / (float)max_steps;
+        dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
+        Cf = (float)C; Hf = (float)H; Hm1 = (float)(H - 1); Hd = (double)H;
+        grid = g;
+    }
+
+    __device__ __forceinline__ int mip_from_pos(float x, float y, float z) const {   // :44-49
+        const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        int e;
+        frexpf(mx, &e);
+        return (int)fminf(Cf - 1, fmaxf(0.0f, (float)e));
+    }
+    __device__ __forceinline__ int mip_from_dt(float dt) const {                     // :51-56 (x0.5 in double is exact)
+        const float mx = (dt * Hf) * 0.5f;
+        int e;
+        frexpf(mx, &e);
+        return (int)fminf(Cf - 1, fmaxf(0.0f, (float)e));
+    }
+    __device__ __forceinline__ int cell(float v, float mip_rbound) const {           // :378-380 (double product)
+        return (int)clampf((float)(0.5 * (double)fmaf(v, mip_rbound, 1.0f) * Hd), 0.0f, Hm1);
+    }
+
+    // Probe at t. Occupied: returns true with x,y,z,dt set (caller advances t += dt).
+    // Empty: t is advanced past the next voxel boundary (:386-403) and false is returned.
+    __device__ __forceinline__ bool probe(float& t, float& x, float& y, float& z, float& dt) const {
+        x = clampf(fmaf(t, dx, ox), -bound, bound);
+        y = clampf(fmaf(t, dy, oy), -bound, bound);
+        z = clampf(fmaf(t, dz, oz), -bound, bound);
+        dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const int lp = mip_from_pos(x, y, z), ld = mip_from_dt(dt);
+        const int level = lp > ld ? lp : ld;
+        const float mip_bound = fminf((float)(1 << level), bound);
+        const float mip_rbound = 1 / mip_bound;
+        const int nx = cell(x, mip_rbound), ny = cell(y, mip_rbound), nz = cell(z, mip_rbound);
+        const uint32_t index = (uint32_t)((float)level * H3f + (float)morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const bool occ = (grid[index >> 3] & (1u << (index & 7u))) != 0;
+        if (!occ) {
+            const float tx = fmaf(fmaf(0.5f, signf(dx), (float)nx + 0.5f) * rH * 2 - 1, mip_bound, -x) * rdx;
+            const float ty = fmaf(fmaf(0.5f, signf(dy), (float)ny + 0.5f) * rH * 2 - 1, mip_bound, -y) * rdy;
+            const float tz = fmaf(fmaf(0.5f, signf(dz), (float)nz + 0.5f) * rH * 2 - 1, mip_bound, -z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+        }
+        return occ;
+    }
+};
+
+}  // namespace ngp

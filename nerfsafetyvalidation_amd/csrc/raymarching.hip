@@ -1,0 +1,555 @@
+// raymarching.hip -- the _raymarching entry points for gfx950.
+//
+// One 64-lane wave handles 64 rays; blocks are 256 threads (4 waves, one per SIMD).
+// All kernels are streaming / latency-bound integer+fp32 work: no LDS tiling, no MFMA.
+// References are to /root/reference/raymarching/src/raymarching.cu.
+#include "ngp_common.hpp"
+
+namespace ngp {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ :93-147
+__global__ void __launch_bounds__(kBlock) k_near_far_from_aabb(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                               const float* __restrict__ aabb, uint32_t N, float min_near,
+                                                               float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
+    const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
+    float near = (a0 - ox) * rdx, far = (a3 - ox) * rdx;
+    if (near > far) { float c = near; near = far; far = c; }
+    float near_y = (a1 - oy) * rdy, far_y = (a4 - oy) * rdy;
+    if (near_y > far_y) { float c = near_y; near_y = far_y; far_y = c; }
+    const float FMAX = 3.402823466e+38f;
+    if (near > far_y || near_y > far) { nears[n] = fars[n] = FMAX; return; }
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (a2 - oz) * rdz, far_z = (a5 - oz) * rdz;
+    if (near_z > far_z) { float c = near_z; near_z = far_z; far_z = c; }
+    if (near > far_z || near_z > far) { nears[n] = fars[n] = FMAX; return; }
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    nears[n] = near;
+    fars[n] = far;
+}
+
+// ------------------------------------------------------------------ :164-200
+__global__ void __launch_bounds__(kBlock) k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float radius,
+                                                         uint32_t N, float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float RPI = 0.3183098861837907f;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float B = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+    const float C = fmaf(oz, oz, fmaf(oy, oy, ox * ox)) - radius * radius;
+    const float t = (-B + sqrtf(fmaf(B, B, -(A * C)))) / A;
+    const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+    const float theta = atan2f(sqrtf(fmaf(x, x, z * z)), y);
+    const float phi = atan2f(z, x);
+    coords[n * 2] = fmaf(2 * theta, RPI, -1.0f);
+    coords[n * 2 + 1] = phi * RPI;
+}
+
+// ------------------------------------------------------------------ :216-256
+__global__ void __launch_bounds__(kBlock) k_morton3D(const int32_t* __restrict__ coords, uint32_t N, int32_t* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3D((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+__global__ void __launch_bounds__(kBlock) k_morton3D_invert(const int32_t* __restrict__ indices, uint32_t N, int32_t* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const int32_t ind = indices[n];
+    coords[n * 3] = (int32_t)morton3D_invert((uint32_t)(ind >> 0));
+    coords[n * 3 + 1] = (int32_t)morton3D_invert((uint32_t)(ind >> 1));
+    coords[n * 3 + 2] = (int32_t)morton3D_invert((uint32_t)(ind >> 2));
+}
+
+// ------------------------------------------------------------------ :269-291
+// One lane packs 4 output bytes from 32 consecutive cells (8 x 16-byte loads): both the
+// read (128 B/lane) and the write (4 B/lane) are fully coalesced.
+__global__ void __launch_bounds__(kBlock) k_packbits(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;  // word index
+    const uint32_t n0 = w * 4;
+    if (n0 >= N) return;
+    if (n0 + 4 <= N && ((uintptr_t)bitfield & 3) == 0 && ((uintptr_t)grid & 15) == 0) {
+        const float4* g = reinterpret_cast<const float4*>(grid) + (size_t)w * 8;
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float4 v = g[q];
+            const uint32_t b = (v.x > thresh ? 1u : 0u) | (v.y > thresh ? 2u : 0u) | (v.z > thresh ? 4u : 0u) | (v.w > thresh ? 8u : 0u);
+            word |= b << (q * 4);
+        }
+        reinterpret_cast<uint32_t*>(bitfield)[w] = word;
+    } else {
+        for (uint32_t n = n0; n < N && n < n0 + 4; n++) {
+            uint8_t bits = 0;
+            for (int i = 0; i < 8; i++) bits |= (grid[(size_t)n * 8 + i] > thresh) ? (uint8_t)(1u << i) : 0;
+            bitfield[n] = bits;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ march_rays_train :313-484
+// Phase A: count occupied steps per ray (the reference's first pass) + per-block sums.
+__global__ void __launch_bounds__(kBlock) k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                              const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                              const float* __restrict__ nears, const float* __restrict__ fars,
+                                                              uint32_t perturb, Pcg32 rng, uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wave_sums[kBlock / 64];
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t num_steps = 0;
+    if (n < N) {
+        Dda s;
+        s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
+        const float far = fars[n];
+        float t = nears[n];
+        if (perturb) {
+            rng.advance((int64_t)n);
+            t += s.dt_min * rng.next_float();
+        }
+        float x, y, z, dt;
+        while (t < far && num_steps < max_steps) {
+            if (s.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
+        }
+        counts[n] = num_steps;
+    }
+    // block reduction
+    uint32_t v = num_steps;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int i = 0; i < kBlock / 64; i++) s += wave_sums[i];
+        block_sums[blockIdx.x] = s;
+    }
+}
+
+// Phase B: one block turns block_sums into exclusive offsets (in place) and bumps the
+// reference's two counters the way its atomics leave them.  base[0..1] receive the
+// counter values BEFORE this call (the slot / row bases).
+__global__ void __launch_bounds__(1024) k_march_train_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t N,
+                                                            int32_t* __restrict__ counter, uint32_t* __restrict__ base) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < nblocks; start += 1024) {
+        const uint32_t i = start + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += o;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wid; w++) wave_off += wave_tot[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        base[0] = (uint32_t)counter[0];
+        base[1] = (uint32_t)counter[1];
+        counter[0] += (int32_t)carry_s;
+        counter[1] += (int32_t)N;
+    }
+}
+
+// Phase C: block-local exclusive scan of counts + block offset -> slot; second DDA pass writes.
+__global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                              const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                              const float* __restrict__ nears, const float* __restrict__ fars,
+                                                              uint32_t perturb, Pcg32 rng, const uint32_t* __restrict__ counts,
+                                                              const uint32_t* __restrict__ block_offsets, const uint32_t* __restrict__ base,
+                                                              float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                                                              int32_t* __restrict__ rays) {
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t num_steps = n < N ? counts[n] : 0;
+    uint32_t incl = num_steps;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (uint32_t w = 0; w < wid; w++) wave_off += wave_tot[w];
+    if (n >= N) return;
+    const uint32_t point_index = base[0] + block_offsets[blockIdx.x] + wave_off + incl - num_steps;
+    const uint32_t ray_index = base[1] + n;
+    if (ray_index < N) {
+        rays[ray_index * 3] = (int32_t)n;
+        rays[ray_index * 3 + 1] = (int32_t)point_index;
+        rays[ray_index * 3 + 2] = (int32_t)num_steps;
+    }
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) return;
+
+    Dda s;
+    s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
+    const float far = fars[n];
+    float t = nears[n];
+    if (perturb) {
+        rng.advance((int64_t)n);
+        t += s.dt_min * rng.next_float();
+    }
+    float* pxyz = xyzs + (size_t)point_index * 3;
+    float* pdir = dirs + (size_t)point_index * 3;
+    float* pdel = deltas + (size_t)point_index * 2;
+    uint32_t step = 0;
+    float last_t = t, x, y, z, dt;
+    while (t < far && step < num_steps) {
+        if (s.probe(t, x, y, z, dt)) {
+            pxyz[0] = x; pxyz[1] = y; pxyz[2] = z;
+            pdir[0] = s.dx; pdir[1] = s.dy; pdir[2] = s.dz;
+            t += dt;
+            pdel[0] = dt;
+            pdel[1] = t - last_t;
+            last_t = t;
+            pxyz += 3; pdir += 3; pdel += 2;
+            step++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ :505-582
+__global__ void __launch_bounds__(kBlock) k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                uint32_t M, uint32_t N, float* __restrict__ weights_sum,
+                                                                float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        weights_sum[index] = 0; depth[index] = 0;
+        image[index * 3] = 0; image[index * 3 + 1] = 0; image[index * 3 + 2] = 0;
+        return;
+    }
+    const float* sg = sigmas + offset;
+    const float* rg = rgbs + (size_t)offset * 3;
+    const float* dl = deltas + (size_t)offset * 2;
+    uint32_t step = 0;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    while (step < num_steps) {
+        const float alpha = 1.0f - expf(-sg[0] * dl[0]);
+        const float weight = alpha * T;
+        r = fmaf(weight, rg[0], r); g = fmaf(weight, rg[1], g); b = fmaf(weight, rg[2], b);
+        t += dl[1];
+        d = fmaf(weight, t, d);
+        ws += weight;
+        T *= 1.0f - alpha;
+        if (T < 1e-4f) break;
+        sg++; rg += 3; dl += 2; step++;
+    }
+    weights_sum[index] = ws; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+// ------------------------------------------------------------------ :606-688
+__global__ void __launch_bounds__(kBlock) k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+                                                                const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                uint32_t M, uint32_t N, float* __restrict__ grad_sigmas,
+                                                                float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    const float gws = grad_weights_sum[index];
+    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
+    const float ws_final = weights_sum[index];
+    const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2];
+    const float* sg = sigmas + offset;
+    const float* rg = rgbs + (size_t)offset * 3;
+    const float* dl = deltas + (size_t)offset * 2;
+    float* gs = grad_sigmas + offset;
+    float* gr = grad_rgbs + (size_t)offset * 3;
+    uint32_t step = 0;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+    while (step < num_steps) {
+        const float alpha = 1.0f - expf(-sg[0] * dl[0]);
+        const float weight = alpha * T;
+        r = fmaf(weight, rg[0], r); g = fmaf(weight, rg[1], g); b = fmaf(weight, rg[2], b);
+        ws += weight;
+        T *= 1.0f - alpha;
+        if (T < 1e-4f) break;
+        gr[0] = gi0 * weight; gr[1] = gi1 * weight; gr[2] = gi2 * weight;
+        float acc = gi0 * fmaf(T, rg[0], -(r_final - r));
+        acc = fmaf(gi1, fmaf(T, rg[1], -(g_final - g)), acc);
+        acc = fmaf(gi2, fmaf(T, rg[2], -(b_final - b)), acc);
+        acc = fmaf(gws, 1 - ws_final, acc);
+        gs[0] = dl[0] * acc;
+        sg++; rg += 3; dl += 2; gs++; gr += 3; step++;
+    }
+}
+
+// ------------------------------------------------------------------ march_rays :706-814
+__global__ void __launch_bounds__(kBlock) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+                                                       const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                       const float* __restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                                       uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                       const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                       float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb, Pcg32 rng,
+                                                       uint32_t n_rows /* padded rows / n_step, rounded up */, uint32_t M_padded) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_rows) return;
+    float* pxyz = xyzs + (size_t)n * n_step * 3;
+    float* pdir = dirs + (size_t)n * n_step * 3;
+    float* pdel = deltas + (size_t)n * n_step * 2;
+    uint32_t step = 0;
+    if (n < n_alive) {
+        const int32_t index = rays_alive[n];
+        Dda s;
+        s.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, dt_gamma, max_steps, C, H);
+        float t = rays_t[index];
+        const float far = fars[index];
+        if (perturb) {
+            rng.advance((int64_t)n);
+            t += s.dt_min * rng.next_float();
+        }
+        float last_t = t, x, y, z, dt;
+        while (t < far && step < n_step) {
+            if (s.probe(t, x, y, z, dt)) {
+                pxyz[0] = x; pxyz[1] = y; pxyz[2] = z;
+                pdir[0] = s.dx; pdir[1] = s.dy; pdir[2] = s.dz;
+                t += dt;
+                pdel[0] = dt;
+                pdel[1] = t - last_t;
+                last_t = t;
+                pxyz += 3; pdir += 3; pdel += 2;
+                step++;
+            }
+        }
+    }
+    // zero-fill the unused tail (the reference wrapper hands in torch.zeros buffers)
+    const uint32_t row0 = n * n_step;
+    for (; step < n_step; step++) {
+        if (row0 + step >= M_padded) break;
+        pxyz[0] = 0; pxyz[1] = 0; pxyz[2] = 0;
+        pdir[0] = 0; pdir[1] = 0; pdir[2] = 0;
+        pdel[0] = 0; pdel[1] = 0;
+        pxyz += 3; pdir += 3; pdel += 2;
+    }
+}
+
+// ------------------------------------------------------------------ composite_rays :828-913
+__global__ void __launch_bounds__(kBlock) k_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* __restrict__ rays_alive,
+                                                           float* __restrict__ rays_t, const float* __restrict__ sigmas,
+                                                           const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                           float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                           float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t index = rays_alive[n];
+    const float* sg = sigmas + (size_t)n * n_step;
+    const float* rg = rgbs + (size_t)n * n_step * 3;
+    const float* dl = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index];
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - expf(-sg[0] * dl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dl[1];
+        d = fmaf(weight, t, d);
+        r = fmaf(weight, rg[0], r); g = fmaf(weight, rg[1], g); b = fmaf(weight, rg[2], b);
+        if ((double)T < 1e-4) break;  // :890 compares against a double literal
+        sg++; rg += 3; dl += 2; step++;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+    weights_sum[index] = weight_sum; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+// ------------------------------------------------------------------ get_rays (nerf/utils.py:52-116)
+// i = pixel column + 0.5, j = pixel row + 0.5 (custom_meshgrid(...).t() flattening: pixel p -> (row p / W, col p % W));
+// dir = ((i-cx)/fx, (j-cy)/fy, 1) / |.|, rays_d = R @ dir (directions @ R^T), rays_o = pose[:3,3].
+__global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ poses, uint32_t Bc, float fx, float fy, float cx, float cy,
+                                                     uint32_t H, uint32_t W, const int32_t* __restrict__ pixel_inds, uint32_t n_pix,
+                                                     float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t cam = blockIdx.y;
+    if (p >= n_pix || cam >= Bc) return;
+    const uint32_t pix = pixel_inds ? (uint32_t)pixel_inds[p] : p;
+    const float* P = poses + (size_t)cam * 16;
+    const float i = (float)(pix % W) + 0.5f, j = (float)(pix / W) + 0.5f;
+    const float xs = (i - cx) / fx, ys = (j - cy) / fy, zs = 1.0f;
+    // torch.norm: sqrt(sum of squares) accumulated in order x,y,z
+    const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
+    const float ux = xs / nrm, uy = ys / nrm, uz = zs / nrm;
+    const size_t o = ((size_t)cam * n_pix + p) * 3;
+    // (directions @ R^T)[k] = sum_m dir[m] * R[k][m]
+    rays_d[o + 0] = ux * P[0] + uy * P[1] + uz * P[2];
+    rays_d[o + 1] = ux * P[4] + uy * P[5] + uz * P[6];
+    rays_d[o + 2] = ux * P[8] + uy * P[9] + uz * P[10];
+    rays_o[o + 0] = P[3];
+    rays_o[o + 1] = P[7];
+    rays_o[o + 2] = P[11];
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near, float* nears,
+                           float* fars, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("near_far_from_aabb", s, N);
+    k_near_far_from_aabb<<<div_up(N, kBlock), kBlock, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return check_launch("near_far_from_aabb");
+}
+
+int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null pointer");
+    k_sph_from_ray<<<div_up(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(rays_o, rays_d, radius, N, coords);
+    return check_launch("sph_from_ray");
+}
+
+int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(coords && indices, "morton3D: null pointer");
+    k_morton3D<<<div_up(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(coords, N, indices);
+    return check_launch("morton3D");
+}
+
+int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(coords && indices, "morton3D_invert: null pointer");
+    k_morton3D_invert<<<div_up(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(indices, N, coords);
+    return check_launch("morton3D_invert");
+}
+
+int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(grid && bitfield, "packbits: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("packbits", s, N);
+    k_packbits<<<div_up(div_up(N, 4), kBlock), kBlock, 0, s>>>(grid, N, density_thresh, bitfield);
+    return check_launch("packbits");
+}
+
+size_t ngp_march_rays_train_workspace(uint32_t N) {
+    const size_t nblocks = div_up(N ? N : 1, kBlock);
+    return (size_t)(N + nblocks + 4) * sizeof(uint32_t);
+}
+
+int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
+                         uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
+                         float* deltas, int32_t* rays, int32_t* counter, uint32_t perturb, void* workspace, size_t workspace_bytes,
+                         ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter, "march_rays_train: null pointer");
+    NGP_REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024, "march_rays_train: unsupported cascade/grid size C=%u H=%u", C, H);
+    if (!workspace || workspace_bytes < ngp_march_rays_train_workspace(N)) {
+        set_error("march_rays_train: workspace of %zu bytes needed, %zu given", ngp_march_rays_train_workspace(N), workspace_bytes);
+        return NGP_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nblocks = div_up(N, kBlock);
+    uint32_t* counts = (uint32_t*)workspace;
+    uint32_t* block_sums = counts + N;
+    uint32_t* base = block_sums + nblocks;
+    Pcg32 rng;
+    rng.seed(42u);  // raymarching.cu:489 hard-coded seed
+    ProfScope prof("march_rays_train", s, N);
+    k_march_train_count<<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb, rng,
+                                                   counts, block_sums);
+    k_march_train_scan<<<1, 1024, 0, s>>>(block_sums, nblocks, N, counter, base);
+    k_march_train_write<<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
+                                                   counts, block_sums, base, xyzs, dirs, deltas, rays);
+    return check_launch("march_rays_train");
+}
+
+int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M,
+                                     uint32_t N, float* weights_sum, float* depth, float* image, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("composite_rays_train_forward", s, M);
+    k_composite_train_fwd<<<div_up(N, kBlock), kBlock, 0, s>>>(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
+    return check_launch("composite_rays_train_forward");
+}
+
+int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas, const float* rgbs,
+                                      const float* deltas, const int32_t* rays, const float* weights_sum, const float* image, uint32_t M,
+                                      uint32_t N, float* grad_sigmas, float* grad_rgbs, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs,
+                "composite_rays_train_backward: null pointer");
+    k_composite_train_bwd<<<div_up(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
+                                                                                 weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    return check_launch("composite_rays_train_backward");
+}
+
+int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                   const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
+                   const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, uint32_t M_padded,
+                   ngp_stream_t stream) {
+    (void)nears;
+    if (M_padded == 0 || n_step == 0) return NGP_OK;
+    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, "march_rays: null pointer");
+    NGP_REQUIRE((uint64_t)n_alive * n_step <= M_padded, "march_rays: M_padded=%u smaller than n_alive*n_step", M_padded);
+    NGP_REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024, "march_rays: unsupported cascade/grid size C=%u H=%u", C, H);
+    hipStream_t s = (hipStream_t)stream;
+    Pcg32 rng;
+    rng.seed((uint64_t)perturb);  // raymarching.cu:819
+    const uint32_t n_rows = div_up(M_padded, n_step);
+    ProfScope prof("march_rays", s, (double)n_alive * n_step);
+    k_march_rays<<<div_up(n_rows, kBlock), kBlock, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
+                                                           C, H, grid, fars, xyzs, dirs, deltas, perturb, rng, n_rows, M_padded);
+    return check_launch("march_rays");
+}
+
+int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas, const float* rgbs,
+                       const float* deltas, float* weights_sum, float* depth, float* image, ngp_stream_t stream) {
+    if (n_alive == 0) return NGP_OK;
+    NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "composite_rays: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("composite_rays", s, (double)n_alive * n_step);
+    k_composite_rays<<<div_up(n_alive, kBlock), kBlock, 0, s>>>(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum,
+                                                                depth, image);
+    return check_launch("composite_rays");
+}
+
+int ngp_get_rays(const float* poses, uint32_t Bc, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                 const int32_t* pixel_inds, uint32_t n_pix, float* rays_o, float* rays_d, ngp_stream_t stream) {
+    if (Bc == 0 || n_pix == 0) return NGP_OK;
+    NGP_REQUIRE(poses && rays_o && rays_d, "get_rays: null pointer");
+    NGP_REQUIRE(pixel_inds || n_pix == H * W, "get_rays: n_pix must be H*W when pixel_inds is NULL");
+    dim3 grid(div_up(n_pix, kBlock), Bc);
+    k_get_rays<<<grid, kBlock, 0, (hipStream_t)stream>>>(poses, Bc, fx, fy, cx, cy, H, W, pixel_inds, n_pix, rays_o, rays_d);
+    return check_launch("get_rays");
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// shencoder.hip -- real spherical-harmonics direction encoding, degree 1..8, for gfx950.
+// References are to /root/reference/shencoder/src/shencoder.cu.
+//
+// The reference hard-codes one Cartesian polynomial per output (:51-121) and its three
+// partial derivatives (:130-355).  All of them have the product form
+//     Y_l^m(x,y,z) = K_l^m * Q_l^|m|(z) * { A_m(x,y) if m > 0 | 1 if m == 0 | B_|m|(x,y) if m < 0 }
+// with A_m + i B_m = (x + i y)^m, Q_l^m = d^m P_l / dz^m and the Condon-Shortley sign (-1)^m
+// folded into K (e.g. :53-56 give -y, +z, -x for l = 1).  We evaluate that form with fully
+// unrolled compile-time recurrences; K is tabulated once on the host in double precision.
+// Output index l*l + l + m; dy_dx layout [B][3][C*C] (:127-129).
+#include <math.h>
+
+#include "ngp_common.hpp"
+
+namespace ngp {
+
+constexpr int kShBlock = 256;
+
+struct ShConst {
+    float K[64];
+};
+
+template <int DEG>
+struct ShBasis {
+    float A[DEG + 1], Bm[DEG + 1];
+    float Q[DEG][DEG + 1];
+
+    __device__ __forceinline__ void build(float x, float y, float z) {
+        A[0] = 1.0f; Bm[0] = 0.0f;
+#pragma unroll
+        for (int m = 1; m <= DEG; m++) {
+            A[m] = x * A[m - 1] - y * Bm[m - 1];
+            Bm[m] = x * Bm[m - 1] + y * A[m - 1];
+        }
+#pragma unroll
+        for (int l = 0; l < DEG; l++)
+#pragma unroll
+            for (int m = 0; m <= DEG; m++) Q[l][m] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < DEG; m++) {
+            float qmm = 1.0f;
+#pragma unroll
+            for (int k = 1; k <= m; k++) qmm *= (float)(2 * k - 1);
+            Q[m][m] = qmm;
+            if (m + 1 < DEG) Q[m + 1][m] = (float)(2 * m + 1) * z * qmm;
+#pragma unroll
+            for (int l = m + 2; l < DEG; l++)
+                Q[l][m] = ((float)(2 * l - 1) * z * Q[l - 1][m] - (float)(l + m - 1) * Q[l - 2][m]) * (1.0f / (float)(l - m));
+        }
+    }
+};
+
+// value of output i = l*l+l+m and (optionally) its gradient
+template <int DEG, bool GRAD>
+__device__ __forceinline__ void sh_term(const ShBasis<DEG>& s, const ShConst& k, int l, int m, float& y, float& gx, float& gy, float& gz) {
+    const int am = m < 0 ? -m : m;
+    const float K = k.K[l * l + l + m];
+    const float q = s.Q[l][am];
+    float ang, ax, ay;
+    if (m == 0) { ang = 1.0f; ax = 0.0f; ay = 0.0f; }
+    else if (m > 0) { ang = s.A[am]; ax = (float)am * s.A[am - 1]; ay = -(float)am * s.Bm[am - 1]; }
+    else { ang = s.Bm[am]; ax = (float)am * s.Bm[am - 1]; ay = (float)am * s.A[am - 1]; }
+    const float Kq = K * q;
+    y = Kq * ang;
+    if (GRAD) {
+        gx = Kq * ax;
+        gy = Kq * ay;
+        gz = K * s.Q[l][am + 1] * ang;  // dQ_l^m/dz = Q_l^{m+1}
+    }
+}
+
+template <int DEG, bool GRAD>
+__global__ void __launch_bounds__(kShBlock) k_sh_forward(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B,
+                                                         uint32_t D, ShConst k, float* __restrict__ dy_dx) {
+    const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
+    if (b >= B) return;
+    constexpr int C2 = DEG * DEG;
+    const float x = inputs[(size_t)b * D], y = inputs[(size_t)b * D + 1], z = inputs[(size_t)b * D + 2];
+    ShBasis<DEG> s;
+    s.build(x, y, z);
+    float* out = outputs + (size_t)b * C2;
+    float* dx = GRAD ? dy_dx + (size_t)b * D * C2 : nullptr;
+#pragma unroll
+    for (int l = 0; l < DEG; l++) {
+#pragma unroll
+        for (int m = -l; m <= l; m++) {
+            float v, gx, gy, gz;
+            sh_term<DEG, GRAD>(s, k, l, m, v, gx, gy, gz);
+            const int i = l * l + l + m;
+            out[i] = v;
+            if (GRAD) { dx[i] = gx; dx[C2 + i] = gy; dx[2 * C2 + i] = gz; }
+        }
+    }
+}
+
+// :359-383 -- accumulates into grad_inputs (the wrapper passes zeros)
+__global__ void __launch_bounds__(kShBlock) k_sh_backward(const float* __restrict__ grad, uint32_t B, uint32_t D, uint32_t C2,
+                                                          const float* __restrict__ dy_dx, float* __restrict__ grad_inputs) {
+    const uint32_t t = blockIdx.x * kShBlock + threadIdx.x;
+    const uint32_t b = t / D;
+    if (b >= B) return;
+    const uint32_t d = t - b * D;
+    const float* g = grad + (size_t)b * C2;
+    const float* dd = dy_dx + (size_t)b * D * C2 + (size_t)d * C2;
+    float acc = grad_inputs[t];
+    for (uint32_t ch = 0; ch < C2; ch++) acc = fmaf(g[ch], dd[ch], acc);
+    grad_inputs[t] = acc;
+}
+
+static const ShConst& sh_constants() {
+    static ShConst k;
+    static bool init = false;
+    if (!init) {
+        for (int l = 0; l < 8; l++)
+            for (int m = -l; m <= l; m++) {
+                const int am = m < 0 ? -m : m;
+                double fact = 1.0;
+                for (int j = l - am + 1; j <= l + am; j++) fact *= j;
+                double K = sqrt((2.0 * l + 1.0) / (4.0 * 3.14159265358979323846) / fact);
+                if (am) K *= sqrt(2.0) * ((am & 1) ? -1.0 : 1.0);
+                k.K[l * l + l + m] = (float)K;
+            }
+        init = true;
+    }
+    return k;
+}
+
+template <int DEG>
+static void launch_sh(const float* in, float* out, uint32_t B, uint32_t D, bool grad, float* dy_dx, hipStream_t s) {
+    const ShConst& k = sh_constants();
+    if (grad) k_sh_forward<DEG, true><<<div_up(B, kShBlock), kShBlock, 0, s>>>(in, out, B, D, k, dy_dx);
+    else k_sh_forward<DEG, false><<<div_up(B, kShBlock), kShBlock, 0, s>>>(in, out, B, D, k, nullptr);
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, int calc_grad_inputs, float* dy_dx,
+                          ngp_stream_t stream) {
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && outputs, "sh_encode_forward: null pointer");
+    NGP_REQUIRE(D == 3, "SH encoder only support input dim == 3");
+    NGP_REQUIRE(C >= 1 && C <= 8, "SH encoder only supports degree in [1, 8]");
+    NGP_REQUIRE(!calc_grad_inputs || dy_dx, "sh_encode_forward: dy_dx is NULL but calc_grad_inputs is set");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("sh_encode_forward", s, B);
+    const bool g = calc_grad_inputs != 0;
+    switch (C) {
+        case 1: launch_sh<1>(inputs, outputs, B, D, g, dy_dx, s); break;
+        case 2: launch_sh<2>(inputs, outputs, B, D, g, dy_dx, s); break;
+        case 3: launch_sh<3>(inputs, outputs, B, D, g, dy_dx, s); break;
+        case 4: launch_sh<4>(inputs, outputs, B, D, g, dy_dx, s); break;
+        case 5: launch_sh<5>(inputs, outputs, B, D, g, dy_dx, s); break;
+        case 6: launch_sh<6>(inputs, outputs, B, D, g, dy_dx, s); break;
+        case 7: launch_sh<7>(inputs, outputs, B, D, g, dy_dx, s); break;
+        default: launch_sh<8>(inputs, outputs, B, D, g, dy_dx, s); break;
+    }
+    return check_launch("sh_encode_forward");
+}
+
+int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx,
+                           float* grad_inputs, ngp_stream_t stream) {
+    (void)inputs;
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(grad && dy_dx && grad_inputs, "sh_encode_backward: null pointer");
+    NGP_REQUIRE(D == 3, "SH encoder only support input dim == 3");
+    NGP_REQUIRE(C >= 1 && C <= 8, "SH encoder only supports degree in [1, 8]");
+    k_sh_backward<<<div_up(B * D, kShBlock), kShBlock, 0, (hipStream_t)stream>>>(grad, B, D, C * C, dy_dx, grad_inputs);
+    return check_launch("sh_encode_backward");
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+"""`gridencoder` operator API on MI355X (reference: gridencoder/grid.py:19-156).
+
+GridEncoder keeps the reference's constructor, parameters (`embeddings` [n, level_dim],
+U(-1e-4, 1e-4)), `offsets` buffer, `output_dim` and forward(inputs, bound=1) contract.
+The native call is ngp_grid_encode_forward/backward (include/ngp_hip.h).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from .. import _lib
+
+_gridtype_to_id = {"hash": 0, "tiled": 1}
+
+
+class _grid_encode(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False):
+        """inputs [B,D] float in [0,1]; embeddings [sO,C]; offsets int32 [L+1] -> [B, L*C]  (grid.py:19-59)"""
+        inputs = inputs.contiguous()
+        if inputs.dtype != torch.float32:
+            inputs = inputs.float()  # "inputs must be float for enough precision" (grid.py:35)
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))  # crosses the ABI as a C float, as in the reference (grid.py:33)
+        H = base_resolution
+
+        # manual autocast: half embeddings only when C is even (grid.py:36-39)
+        if torch.is_autocast_enabled("cuda") and C % 2 == 0:
+            embeddings = embeddings.to(torch.half)
+        embeddings = embeddings.contiguous()
+
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
+
+        lib = _lib.lib()
+        _lib.check(lib.ngp_grid_encode_forward(_lib.ptr(inputs), _lib.ptr(embeddings), _lib.host_i32(offsets), _lib.ptr(outputs),
+                                               B, D, C, L, S, H, int(calc_grad_inputs), _lib.ptr(dy_dx), gridtype,
+                                               int(align_corners), _lib.dtype_code(embeddings), _lib.stream()),
+                   "grid_encode_forward")
+
+        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)  # [L,B,C] -> [B, L*C] (grid.py:52)
+
+        if dy_dx is None:
+            dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)  # placeholder, as the reference saves
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = [B, D, C, L, S, H, gridtype]
+        ctx.calc_grad_inputs = calc_grad_inputs
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype = ctx.dims
+        calc_grad_inputs = ctx.calc_grad_inputs
+
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous().to(embeddings.dtype)  # -> [L,B,C] (grid.py:72)
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if calc_grad_inputs else None
+
+        lib = _lib.lib()
+        _lib.check(lib.ngp_grid_encode_backward(_lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings), _lib.host_i32(offsets),
+                                                _lib.ptr(grad_embeddings), B, D, C, L, S, H, int(calc_grad_inputs),
+                                                _lib.ptr(dy_dx) if calc_grad_inputs else None, _lib.ptr(grad_inputs), gridtype,
+                                                int(ctx.align_corners), _lib.dtype_code(embeddings), _lib.stream()),
+                   "grid_encode_backward")
+        if calc_grad_inputs:
+            return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None
+        return None, grad_embeddings, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    """Multiresolution hash / tiled grid (gridencoder/grid.py:93-156)."""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype="hash", align_corners=False):
+        super().__init__()
+        if desired_resolution is not None:  # overrides per_level_scale (grid.py:97-99)
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.align_corners = align_corners
+
+        # level table (grid.py:113-124): entries per level capped at 2^log2_hashmap_size, rounded up to 8
+        self.max_params = 2 ** log2_hashmap_size
+        offsets, offset = [], 0
+        for i in range(num_levels):
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            params_in_level = min(self.max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+            params_in_level = int(np.ceil(params_in_level / 8) * 8)
+            offsets.append(offset)
+            offset += params_in_level
+        offsets.append(offset)
+        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> "
+                f"{int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} "
+                f"gridtype={self.gridtype} align_corners={self.align_corners}")
+
+    def forward(self, inputs, bound=1):
+        """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels*level_dim]"""
+        inputs = (inputs + bound) / (2 * bound)
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, self.align_corners)
+        return outputs.view(prefix_shape + [self.output_dim])

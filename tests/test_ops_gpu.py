@@ -1,0 +1,312 @@
+"""Parity of every HIP operator against the CPU oracle, through the Python operator API (which calls the
+C ABI of libngp_hip.so).  Integer / index / sample-position outputs are compared bit for bit; floating
+point outputs with the tolerance written next to each assert."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(H=48, W=48, bound=2):
+    from nerfsafetyvalidation_amd.scene import StonehengeScene
+    return StonehengeScene(H=H, W=W, bound=bound)
+
+
+def _rays(scene, view=7):
+    return Hh.pinhole_rays(scene.poses[view], scene.intrinsics, scene.H, scene.W)
+
+
+def _t(x, device):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device)
+
+
+def test_native_library_is_loaded(device):
+    from nerfsafetyvalidation_amd import _lib
+    L = _lib.lib()
+    assert L.ngp_version() >= 100
+    assert L.ngp_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libngp_hip.so" in maps
+
+
+def test_near_far_bit_exact(device):
+    from nerfsafetyvalidation_amd import raymarching
+    rng = np.random.default_rng(0)
+    N = 10007
+    rays_o = rng.uniform(-2.5, 2.5, (N, 3)).astype(np.float32)
+    rays_d = rng.normal(size=(N, 3)).astype(np.float32)
+    rays_d /= np.linalg.norm(rays_d, axis=-1, keepdims=True)
+    rays_d[:5] = [[1, 0, 0], [0, 1, 0], [0, 0, -1], [1, 0, 0], [0, -1, 0]]  # axis-aligned: 1/0 = inf slabs
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    O.near_far_from_aabb(rays_o, rays_d, aabb, N, 0.2, nears, fars)
+    n_gpu, f_gpu = raymarching.near_far_from_aabb(_t(rays_o, device), _t(rays_d, device), _t(aabb, device), 0.2)
+    assert (nears == np.finfo(np.float32).max).sum() > 100  # misses are exercised
+    # NaN-free comparison of raw bits
+    assert np.array_equal(n_gpu.cpu().numpy().view(np.uint32), nears.view(np.uint32))
+    assert np.array_equal(f_gpu.cpu().numpy().view(np.uint32), fars.view(np.uint32))
+
+
+def test_morton_and_packbits_bit_exact(device):
+    from nerfsafetyvalidation_amd import raymarching
+    rng = np.random.default_rng(1)
+    coords = rng.integers(0, 128, (5000, 3)).astype(np.int32)
+    idx = np.empty(5000, np.int32)
+    O.morton3D(coords, 5000, idx)
+    idx_gpu = raymarching.morton3D(_t(coords, device))
+    assert np.array_equal(idx_gpu.cpu().numpy(), idx)
+    back = raymarching.morton3D_invert(idx_gpu)
+    assert np.array_equal(back.cpu().numpy(), coords)
+    # packbits incl. values equal to the threshold (strict >) and a size that is not a multiple of 4 bytes
+    for cells in (128 ** 3, 8 * 1003):
+        grid = rng.uniform(0, 0.02, (1, cells)).astype(np.float32)
+        grid[0, ::17] = 0.01
+        bits = np.empty(cells // 8, np.uint8)
+        O.packbits(grid, cells // 8, 0.01, bits)
+        bits_gpu = raymarching.packbits(_t(grid, device), 0.01)
+        assert np.array_equal(bits_gpu.cpu().numpy(), bits)
+    # empty input
+    assert raymarching.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=device)).numel() == 0
+
+
+@pytest.mark.parametrize("dt_gamma,perturb", [(0.0, 0), (1.0 / 128, 0), (0.0, 3)])
+def test_march_rays_bit_exact(device, dt_gamma, perturb):
+    from nerfsafetyvalidation_amd import raymarching
+    sc = _scene()
+    rays_o, rays_d = _rays(sc)
+    N = rays_o.shape[0]
+    bitfield = sc.bitfield()
+    aabb = np.array([-sc.bound] * 3 + [sc.bound] * 3, np.float32)
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    O.near_far_from_aabb(rays_o, rays_d, aabb, N, 0.2, nears, fars)
+    rng = np.random.default_rng(2)
+    alive = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int32)
+    n_alive, n_step = alive.shape[0], 3
+    M = n_alive * n_step
+    M += 128 - M % 128
+    xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+    O.march_rays(n_alive, n_step, alive, nears, rays_o, rays_d, sc.bound, dt_gamma, 1024, sc.cascade, 128, bitfield, nears, fars, xyzs,
+                 dirs, deltas, perturb)
+    assert (deltas[:, 0] > 0).sum() > 200  # the scene is hit
+    g = raymarching.march_rays(n_alive, n_step, _t(alive, device), _t(nears, device), _t(rays_o, device), _t(rays_d, device), sc.bound,
+                               _t(bitfield, device), sc.cascade, 128, _t(nears, device), _t(fars, device), 128, perturb, dt_gamma, 1024)
+    for got, want in zip(g, (xyzs, dirs, deltas)):
+        assert got.shape == want.shape
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_march_rays_train_bit_exact(device, perturb):
+    from nerfsafetyvalidation_amd import raymarching
+    sc = _scene()
+    rays_o, rays_d = _rays(sc, view=33)
+    N = rays_o.shape[0]
+    bitfield = sc.bitfield()
+    aabb = np.array([-sc.bound] * 3 + [sc.bound] * 3, np.float32)
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    O.near_far_from_aabb(rays_o, rays_d, aabb, N, 0.2, nears, fars)
+    max_steps = 256
+    M = N * max_steps
+    xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+    rays = np.zeros((N, 3), np.int32)
+    counter = np.zeros(2, np.int32)
+    O.march_rays_train(rays_o, rays_d, bitfield, sc.bound, 0.0, max_steps, N, sc.cascade, 128, M, nears, fars, xyzs, dirs, deltas, rays,
+                       counter, int(perturb))
+    m = int(counter[0])
+    assert m > 1000 and counter[1] == N
+    counter_gpu = torch.zeros(2, dtype=torch.int32, device=device)
+    gx, gd, gdl, grays = raymarching.march_rays_train(_t(rays_o, device), _t(rays_d, device), sc.bound, _t(bitfield, device), sc.cascade,
+                                                      128, _t(nears, device), _t(fars, device), counter_gpu, -1, perturb, 128, True, 0.0,
+                                                      max_steps)
+    assert np.array_equal(counter_gpu.cpu().numpy(), counter)
+    assert np.array_equal(grays.cpu().numpy(), rays)  # index -> offset -> count, bit exact (prefix-sum order)
+    m_pad = m + 128 - m % 128
+    assert gx.shape[0] == m_pad
+    assert np.array_equal(gx.cpu().numpy().view(np.uint32), xyzs[:m_pad].view(np.uint32))
+    assert np.array_equal(gd.cpu().numpy().view(np.uint32), dirs[:m_pad].view(np.uint32))
+    assert np.array_equal(gdl.cpu().numpy().view(np.uint32), deltas[:m_pad].view(np.uint32))
+
+    # mean_count capacity: rays whose slab does not fit are dropped the same way (raymarching.cu:421)
+    cap = (m // 2) - (m // 2) % 128
+    xyzs2, dirs2, deltas2 = np.zeros((cap + 128, 3), np.float32), np.zeros((cap + 128, 3), np.float32), np.zeros((cap + 128, 2), np.float32)
+    rays2, counter2 = np.zeros((N, 3), np.int32), np.zeros(2, np.int32)
+    O.march_rays_train(rays_o, rays_d, bitfield, sc.bound, 0.0, max_steps, N, sc.cascade, 128, cap + 128, nears, fars, xyzs2, dirs2, deltas2,
+                       rays2, counter2, int(perturb))
+    c2 = torch.zeros(2, dtype=torch.int32, device=device)
+    gx2, _, gdl2, grays2 = raymarching.march_rays_train(_t(rays_o, device), _t(rays_d, device), sc.bound, _t(bitfield, device), sc.cascade,
+                                                        128, _t(nears, device), _t(fars, device), c2, cap, perturb, 128, False, 0.0,
+                                                        max_steps)
+    assert gx2.shape[0] == cap + 128
+    assert np.array_equal(grays2.cpu().numpy(), rays2)
+    assert np.array_equal(gx2.cpu().numpy().view(np.uint32), xyzs2.view(np.uint32))
+    assert np.array_equal(gdl2.cpu().numpy().view(np.uint32), deltas2.view(np.uint32))
+
+    # composite_rays_train forward / backward on those samples
+    rng = np.random.default_rng(3)
+    sig = rng.uniform(0, 60, m_pad).astype(np.float32)
+    rgb = rng.uniform(0, 1, (m_pad, 3)).astype(np.float32)
+    ws, dp, im = np.empty(N, np.float32), np.empty(N, np.float32), np.empty((N, 3), np.float32)
+    O.composite_rays_train_forward(sig, rgb, deltas[:m_pad].copy(), rays, m_pad, N, ws, dp, im)
+    ts, tr = _t(sig, device).requires_grad_(True), _t(rgb, device).requires_grad_(True)
+    gws, gdp, gim = raymarching.composite_rays_train(ts, tr, gdl, grays)
+    # tolerance: device expf vs glibc expf (<= 2 ulp each) through <= 256 accumulations
+    np.testing.assert_allclose(gws.detach().cpu().numpy(), ws, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(gdp.detach().cpu().numpy(), dp, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(gim.detach().cpu().numpy(), im, rtol=2e-5, atol=2e-6)
+    g_ws, g_im = rng.normal(size=N).astype(np.float32), rng.normal(size=(N, 3)).astype(np.float32)
+    gs, gr = np.zeros(m_pad, np.float32), np.zeros((m_pad, 3), np.float32)
+    O.composite_rays_train_backward(g_ws, g_im, sig, rgb, deltas[:m_pad].copy(), rays, ws, im, m_pad, N, gs, gr)
+    (gws * _t(g_ws, device)).sum().add((gim * _t(g_im, device)).sum()).backward()
+    np.testing.assert_allclose(tr.grad.cpu().numpy(), gr, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ts.grad.cpu().numpy(), gs, rtol=1e-3, atol=2e-5)
+
+
+def test_composite_rays_inplace(device):
+    from nerfsafetyvalidation_amd import raymarching
+    rng = np.random.default_rng(4)
+    N, n_alive, n_step = 4000, 1500, 4
+    alive = np.sort(rng.choice(N, n_alive, replace=False)).astype(np.int32)
+    M = n_alive * n_step + 128
+    sig = rng.uniform(0, 2500, M).astype(np.float32)
+    rgb = rng.uniform(0, 1, (M, 3)).astype(np.float32)
+    deltas = np.full((M, 2), 0.0033829117, np.float32)
+    deltas[rng.uniform(size=M) < 0.05] = 0  # terminated-by-march markers
+    state = dict(rays_t=rng.uniform(0.2, 3, N).astype(np.float32), ws=rng.uniform(0, 0.9, N).astype(np.float32),
+                 depth=rng.uniform(0, 1, N).astype(np.float32), image=rng.uniform(0, 1, (N, 3)).astype(np.float32))
+    o_alive, o = alive.copy(), {k: v.copy() for k, v in state.items()}
+    O.composite_rays(n_alive, n_step, o_alive, o["rays_t"], sig, rgb, deltas, o["ws"], o["depth"], o["image"])
+    g_alive = _t(alive, device)
+    g = {k: _t(v, device) for k, v in state.items()}
+    ret = raymarching.composite_rays(n_alive, n_step, g_alive, g["rays_t"], _t(sig, device), _t(rgb, device), _t(deltas, device), g["ws"],
+                                     g["depth"], g["image"])
+    assert ret == tuple()
+    # termination flags: identical except rays whose transmittance sits within 1e-6 of the 1e-4 threshold
+    diff = g_alive.cpu().numpy() != o_alive
+    assert diff.sum() <= 2
+    assert (o_alive == -1).sum() > 50 and (o_alive >= 0).sum() > 50
+    for k in state:
+        np.testing.assert_allclose(g[k].cpu().numpy()[~np.isin(np.arange(N), alive[diff])], o[k][~np.isin(np.arange(N), alive[diff])],
+                                   rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("D,C", [(3, 2), (3, 1), (3, 4), (3, 8), (2, 2)])
+def test_grid_encode_forward_bit_exact(device, dtype, D, C):
+    from nerfsafetyvalidation_amd.gridencoder import grid_encode
+    rng = np.random.default_rng(5)
+    L, log2T = (16, 19) if D == 3 else (8, 15)
+    offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=log2T, desired_resolution=2048)
+    emb = rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32).astype(dtype)
+    B = 3001
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = 1.0            # exactly 1 is in range (gridencoder.cu:102 tests > 1)
+    x[2, 0] = 1.0000001   # out of range -> zeros
+    x[3, 1] = -1e-7
+    x[4] = 0.5
+    want, want_dydx = Hh.oracle_grid_encode(x, emb, offsets, pls, calc_grad=True)
+    xt = _t(x, device).requires_grad_(True)
+    out = grid_encode(xt, _t(emb, device), _t(offsets, device), pls, 16, True, 0, False)
+    assert out.shape == (B, L * C)
+    got = out.detach().cpu().numpy()
+    bits = np.uint32 if dtype == np.float32 else np.uint16
+    mism = got.view(bits) != want.view(bits)
+    # -0.0 vs +0.0 cannot occur; demand exact equality of the bit patterns
+    assert mism.sum() == 0, f"{mism.sum()} of {mism.size} outputs differ; max abs diff {np.abs(got.astype(np.float64) - want).max()}"
+    assert np.all(got[2] == 0) and np.all(got[3] == 0)
+    # tiled grid type + align_corners
+    want2, _ = Hh.oracle_grid_encode(x, emb, offsets, pls, gridtype=1, align_corners=True)
+    got2 = grid_encode(_t(x, device), _t(emb, device), _t(offsets, device), pls, 16, False, 1, True).cpu().numpy()
+    assert np.array_equal(got2.view(bits), want2.view(bits))
+    # input gradient through dy_dx (kernel_input_backward) and table gradient (atomics: tolerance)
+    if C != 1 or dtype == np.float32:
+        g = rng.normal(size=(B, L * C)).astype(np.float32)
+        embt = _t(emb, device).requires_grad_(True)
+        out = grid_encode(xt, embt, _t(offsets, device), pls, 16, True, 0, False)
+        out.backward(_t(g.astype(dtype), device))
+        gl = np.ascontiguousarray(g.astype(dtype).reshape(B, L, C).transpose(1, 0, 2))
+        ge, gi = np.zeros_like(emb), np.zeros((B, D), dtype)
+        O.grid_encode_backward(gl, x, emb, offsets, ge, B, D, C, L, float(np.log2(pls)), 16, True, want_dydx, gi, 0, False)
+        tol = dict(rtol=1e-4, atol=1e-5) if dtype == np.float32 else dict(rtol=2e-2, atol=2e-2)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), gi.astype(np.float32), **tol)
+        np.testing.assert_allclose(embt.grad.cpu().numpy().astype(np.float32), ge.astype(np.float32),
+                                   **(dict(rtol=1e-4, atol=1e-5) if dtype == np.float32 else dict(rtol=5e-2, atol=5e-2)))
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_encode(device, degree):
+    from nerfsafetyvalidation_amd.shencoder import sh_encode
+    rng = np.random.default_rng(6)
+    B = 2049
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    C2 = degree * degree
+    want, dydx = np.empty((B, C2), np.float32), np.empty((B, 3 * C2), np.float32)
+    O.sh_encode_forward(d, want, B, 3, degree, True, dydx)
+    xt = _t(d, device).requires_grad_(True)
+    out = sh_encode(xt, degree, True)
+    # fp32 recurrences vs the oracle's double evaluation: values are O(1..10), tolerance 1e-5 relative to the largest
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=2e-5)
+    g = rng.normal(size=(B, C2)).astype(np.float32)
+    out.backward(_t(g, device))
+    gi = np.zeros((B, 3), np.float32)
+    O.sh_encode_backward(g, d, B, 3, degree, dydx, gi)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), gi, rtol=1e-4, atol=2e-4 * degree)
+
+
+@pytest.mark.parametrize("hidden,in_dim,num_layers,B", [(64, 32, 2, 1000), (64, 32, 3, 128), (16, 16, 2, 77), (32, 48, 4, 300),
+                                                        (128, 32, 2, 256), (256, 64, 2, 130)])
+def test_ffmlp_inference_and_forward(device, hidden, in_dim, num_layers, B):
+    from nerfsafetyvalidation_amd.ffmlp import FFMLP
+    rng = np.random.default_rng(7)
+    net = FFMLP(in_dim, 13, hidden, num_layers).to(device)
+    x = rng.uniform(-1, 1, (B, in_dim)).astype(np.float32)
+    w16 = net.weights.detach().cpu().half().numpy()
+    want = Hh.oracle_ffmlp(x.astype(np.float16), w16, in_dim, hidden, num_layers)[:, :13]
+    with torch.autocast("cuda", dtype=torch.float16):
+        net.eval()
+        got_inf = net(_t(x, device))
+        net.train()
+        got_fwd = net(_t(x, device))
+    assert got_inf.shape == (B, 13) and got_inf.dtype == torch.float16
+    assert torch.equal(got_inf.detach(), got_fwd.detach())
+    got = got_inf.detach().float().cpu().numpy()
+    # fp32 MFMA accumulation vs the oracle's exact sum: a hidden unit can land on the other side of an fp16
+    # rounding boundary (1 fp16 ulp = 2^-11 relative); outputs are O(1)
+    np.testing.assert_allclose(got, want.astype(np.float32), rtol=4e-3, atol=4e-3)
+    assert (got == want.astype(np.float32)).mean() > 0.5
+
+
+def test_ffmlp_rejects_bad_shapes(device):
+    from nerfsafetyvalidation_amd.ffmlp import FFMLP
+    with pytest.raises(AssertionError):
+        FFMLP(32, 16, 48, 2)
+    with pytest.raises(AssertionError):
+        FFMLP(20, 16, 64, 2)
+    net = FFMLP(32, 16, 64, 2).to(device).eval()
+    with pytest.raises(RuntimeError):  # not under autocast and not half: the reference's CHECK_IS_HALF
+        net(torch.zeros(4, 32, device=device))
+
+
+def test_get_rays(device):
+    from nerfsafetyvalidation_amd.nerf.utils import get_rays
+    sc = _scene(H=40, W=56)
+    poses = torch.from_numpy(sc.poses[[0, 57, 123]]).to(device)
+    out = get_rays(poses, sc.intrinsics, sc.H, sc.W)
+    assert out["rays_o"].shape == (3, sc.H * sc.W, 3)
+    for b, v in enumerate([0, 57, 123]):
+        ro, rd = Hh.pinhole_rays(sc.poses[v], sc.intrinsics, sc.H, sc.W)
+        # torch builds the same rays with a batched matmul; agreement to a few fp32 ulp
+        np.testing.assert_allclose(out["rays_d"][b].cpu().numpy(), rd, rtol=0, atol=3e-7)
+        assert np.array_equal(out["rays_o"][b].cpu().numpy(), ro)
+    sub = get_rays(poses, sc.intrinsics, sc.H, sc.W, inds=torch.tensor([0, 5, sc.H * sc.W - 1]))
+    assert torch.equal(sub["rays_d"], out["rays_d"][:, [0, 5, sc.H * sc.W - 1]])
+    rnd = get_rays(poses, sc.intrinsics, sc.H, sc.W, N=100)
+    assert rnd["rays_d"].shape == (3, 100, 3) and rnd["inds"].shape == (3, 100)
+    assert torch.equal(rnd["rays_d"][1], out["rays_d"][1][rnd["inds"][1]])
