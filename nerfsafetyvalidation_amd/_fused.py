@@ -1,0 +1,158 @@
+"""Host glue for the fused MI355X render entry points (ngp_render_rays / ngp_network_forward).
+
+A FusedModel snapshots what the C ABI's `ngp_model` needs from a NeRFNetwork: the fp16 hash table,
+the two fp16 weight blobs in FFMLP layout, the occupancy bitfield and the scalar hyper-parameters.
+Parameters are re-snapshotted when their torch version counters change, so the object can be cached
+on the module.  The nn.Linear backbone (nerf/network.py) is zero-padded to the fused shapes:
+    sigma : W1 [64,32], W2 [16,64]                        -> blob [64x32 | 16x64]          (0 hidden matmuls)
+    colour: W1 [64,31], W2 [64,64], W3 [3,64]             -> blob [64x32 | 64x64 | 16x64]  (1 hidden matmul)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _versions(tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
+class FusedModel:
+    def __init__(self, net, emb16, sigma_blob, sigma_mm, color_blob, color_mm, watched):
+        enc = net.encoder
+        if enc.input_dim != 3 or enc.num_levels != 16 or enc.level_dim != 2:
+            raise RuntimeError("fused renderer needs the 3-D, 16-level, 2-feature hash grid")
+        self.device = emb16.device
+        self.emb16, self.sigma_blob, self.color_blob = emb16, sigma_blob, color_blob
+        self.sigma_mm, self.color_mm = sigma_mm, color_mm
+        self.offsets_host = _lib.host_i32(enc.offsets)
+        self.S = float(np.log2(enc.per_level_scale))
+        self.H_base = enc.base_resolution
+        self.gridtype = enc.gridtype_id
+        self.align_corners = int(enc.align_corners)
+        self.bound = float(net.bound)
+        self.density_scale = float(net.density_scale)
+        self.cascade, self.grid_size = net.cascade, net.grid_size
+        self._watched = watched
+        self._snapshot = _versions(watched)
+        self._ctx = None
+        self._ctx_rays = 0
+        self._pad = None
+        self.last_stats = None
+
+    # ---- construction from the two backbones ---------------------------------------------------------
+    @classmethod
+    def from_ffmlp_network(cls, net):
+        if net.hidden_dim != 64 or net.hidden_dim_color != 64 or net.in_dim != 32 or net.in_dim_color != 32:
+            raise RuntimeError("fused renderer needs 64-wide FFMLPs on 32-wide inputs")
+        watched = [net.encoder.embeddings, net.sigma_net.weights, net.color_net.weights]
+        return cls(net, net.encoder.embeddings.detach().half().contiguous(), net.sigma_net.weights.detach().half().contiguous(),
+                   net.num_layers - 1, net.color_net.weights.detach().half().contiguous(), net.num_layers_color - 1, watched)
+
+    @classmethod
+    def from_linear_network(cls, net):
+        def blob(layers, in_pad):
+            parts = []
+            for i, layer in enumerate(layers):
+                w = layer.weight.detach().half()
+                rows = 16 if i == len(layers) - 1 else 64
+                cols = in_pad if i == 0 else 64
+                if w.shape[0] > rows or w.shape[1] > cols or (0 < i < len(layers) - 1 and tuple(w.shape) != (64, 64)):
+                    raise RuntimeError(f"layer {i} of shape {tuple(w.shape)} does not fit the fused {rows}x{cols} slot")
+                full = torch.zeros(rows, cols, dtype=torch.half, device=w.device)
+                full[:w.shape[0], :w.shape[1]] = w
+                parts.append(full.reshape(-1))
+            return torch.cat(parts).contiguous()
+
+        if net.hidden_dim != 64 or net.hidden_dim_color != 64 or net.geo_feat_dim != 15:
+            raise RuntimeError("fused renderer needs 64-wide MLPs and geo_feat_dim == 15")
+        watched = [net.encoder.embeddings] + [l.weight for l in net.sigma_net] + [l.weight for l in net.color_net]
+        return cls(net, net.encoder.embeddings.detach().half().contiguous(), blob(net.sigma_net, 32), len(net.sigma_net) - 2,
+                   blob(net.color_net, 32), len(net.color_net) - 2, watched)
+
+    def valid_for(self, net):
+        return (_versions(self._watched) == self._snapshot and self.density_scale == float(net.density_scale)
+                and self.bound == float(net.bound) and self.emb16.device == net.encoder.embeddings.device)
+
+    # ---- C structs -----------------------------------------------------------------------------------------
+    def _struct(self, bitfield):
+        m = _lib.ModelStruct()
+        m.embeddings = _lib.ptr(self.emb16)
+        m.offsets_host = C.cast(self.offsets_host, C.c_void_p)
+        m.L, m.S, m.H_base, m.gridtype, m.align_corners = 16, self.S, self.H_base, self.gridtype, self.align_corners
+        m.sigma_weights, m.sigma_hidden_mm = _lib.ptr(self.sigma_blob), self.sigma_mm
+        m.color_weights, m.color_hidden_mm = _lib.ptr(self.color_blob), self.color_mm
+        m.bound, m.density_scale = self.bound, self.density_scale
+        m.density_bitfield = _lib.ptr(bitfield) if bitfield is not None else None
+        m.cascade, m.grid_size = self.cascade, self.grid_size
+        return m
+
+    def network_forward(self, xyzs, dirs):
+        """fused NeRFNetwork.forward: xyzs, dirs [M,3] f32 -> sigma [M] f32 (unscaled), rgb [M,3] f32 (fp16-rounded)"""
+        xyzs, dirs = xyzs.float().contiguous(), dirs.float().contiguous()
+        M = xyzs.shape[0]
+        sigmas = torch.empty(M, dtype=torch.float32, device=xyzs.device)
+        rgbs = torch.empty(M, 3, dtype=torch.float32, device=xyzs.device)
+        m = self._struct(None)
+        lib = _lib.lib()
+        _lib.check(lib.ngp_network_forward(C.byref(m), _lib.ptr(xyzs), _lib.ptr(dirs), M, _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.stream()),
+                   "network_forward")
+        return sigmas, rgbs
+
+    def _pad_value(self):
+        """what the network returns for the reference's zero-filled padding rows (xyz = 0, dir = 0)"""
+        if self._pad is None:
+            z = torch.zeros(16, 3, device=self.device)
+            s, c = self.network_forward(z, z)
+            sig = np.float32(float(s[0])) * np.float32(self.density_scale)  # fp32 product, as renderer.py:365
+            self._pad = (C.c_float * 4)(float(sig), float(c[0, 0]), float(c[0, 1]), float(c[0, 2]))
+        return self._pad
+
+    def _context(self, N):
+        lib = _lib.lib()
+        if self._ctx is None or self._ctx_rays < N:
+            if self._ctx is not None:
+                lib.ngp_render_ctx_destroy(self._ctx)
+            h = C.c_void_p()
+            _lib.check(lib.ngp_render_ctx_create(N, C.byref(h)), "render_ctx_create")
+            self._ctx, self._ctx_rays = h, N
+        return self._ctx
+
+    def render(self, net_bitfield_owner, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb, want_last=True, want_stats=True):
+        """eval-mode body of run_cuda -> weights_sum [N], depth [N], image [N,3], last sigmas, last rgbs"""
+        bitfield = net_bitfield_owner.density_bitfield
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        last_s = torch.empty(N + 128, dtype=torch.float32, device=dev) if want_last else None
+        last_c = torch.empty(N + 128, 3, dtype=torch.float32, device=dev) if want_last else None
+        stats = _lib.RenderStats()
+        m = self._struct(bitfield)
+        lib = _lib.lib()
+        ctx = self._context(N)
+        need_stats = want_stats or want_last
+        _lib.check(lib.ngp_render_rays(ctx, C.byref(m), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()),
+                                       _lib.ptr(fars.contiguous()), N, float(dt_gamma), int(max_steps), int(perturb), _lib.ptr(weights_sum),
+                                       _lib.ptr(depth), _lib.ptr(image), _lib.ptr(last_s), _lib.ptr(last_c),
+                                       self._pad_value() if want_last else None, C.byref(stats) if need_stats else None, 0, _lib.stream()),
+                   "render_rays")
+        sigmas = rgbs = None
+        if need_stats:
+            self.last_stats = {"samples_marched": int(stats.samples_marched), "samples_slots": int(stats.samples_slots),
+                               "iterations": int(stats.iterations), "rays": int(stats.rays), "launches": int(stats.launches)}
+        if want_last and stats.iterations > 0:
+            M = stats.last_n_alive * stats.last_n_step
+            M += 128 - (M % 128)  # F11
+            sigmas, rgbs = last_s[:M], last_c[:M]
+        return weights_sum, depth, image, sigmas, rgbs
+
+    def __del__(self):
+        try:
+            if self._ctx is not None:
+                _lib.lib().ngp_render_ctx_destroy(self._ctx)
+        except Exception:
+            pass

@@ -20,14 +20,7 @@
 
 namespace ngp {
 
-constexpr int kMaxLevels = 32;
 constexpr int kGridBlock = 256;
-
-struct GridLevels {
-    float scale[kMaxLevels];
-    uint32_t resolution[kMaxLevels];
-    uint32_t offset[kMaxLevels + 1];
-};
 
 template <typename T, int C>
 struct alignas(sizeof(T) * C) Vec {
@@ -63,7 +56,7 @@ __device__ __forceinline__ uint32_t grid_entry(uint32_t gridtype, bool align_cor
 // acc += w * g with the reference's scalar_t semantics (see oracle/ngp_oracle.c acc_mul):
 // f32: one fma; f16: product rounded to half, then a half add.
 __device__ __forceinline__ void acc_mul(float& acc, float w, float g) { acc = fmaf(w, g, acc); }
-__device__ __forceinline__ void acc_mul(_Float16& acc, float w, _Float16 g) { acc = acc + (_Float16)(w * (float)g); }
+__device__ __forceinline__ void acc_mul(_Float16& acc, float w, _Float16 g) { acc = acc + mul_round_f16(w, g); }
 
 // XCD-aware decode of the 1-D grid: returns false when this block has no work.
 __device__ __forceinline__ bool decode_block(uint32_t L, uint32_t& level, uint32_t& point_block) {
@@ -242,15 +235,29 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_input_backward(const T* __r
     grad_inputs[t] = result;
 }
 
-static int fill_levels(GridLevels& lv, const int32_t* offsets_host, uint32_t L, float S, uint32_t H) {
+void fill_levels(GridLevels& lv, const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t D, uint32_t gridtype,
+                 bool align_corners) {
     for (uint32_t l = 0; l < L; l++) {
         const float scale = exp2f((float)l * S) * (float)H - 1.0f;  // :126
         lv.scale[l] = scale;
-        lv.resolution[l] = (uint32_t)ceilf(scale) + 1;              // :127
+        const uint32_t res = (uint32_t)ceilf(scale) + 1;             // :127
+        lv.resolution[l] = res;
         lv.offset[l] = (uint32_t)offsets_host[l];
+        const uint32_t size = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        // replay the stride loop of get_grid_index (:58-62) once per level
+        const uint32_t step = align_corners ? res : res + 1;
+        uint32_t stride = 1, mul[3] = {0, 0, 0};
+        for (uint32_t d = 0; d < D && stride <= size; d++) {
+            mul[d] = stride;
+            stride *= step;
+        }
+        lv.mul1[l] = mul[1];
+        lv.mul2[l] = mul[2];
+        lv.hashed[l] = (gridtype == 0 && stride > size) ? 1 : 0;
+        const bool dense = !lv.hashed[l] && stride <= size;  // every dim consumed and the full index range fits
+        lv.mode[l] = dense ? 0 : ((size & (size - 1)) == 0 ? 1 : 2);
     }
     lv.offset[L] = (uint32_t)offsets_host[L];
-    return 0;
 }
 
 template <typename T, int D, int C>
@@ -304,7 +311,7 @@ int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const i
     NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, "grid_encode_forward: dtype must be NGP_F32 or NGP_F16");
     NGP_REQUIRE(!calc_grad_inputs || dy_dx, "grid_encode_forward: dy_dx is NULL but calc_grad_inputs is set");
     GridLevels lv;
-    fill_levels(lv, offsets_host, L, S, H);
+    fill_levels(lv, offsets_host, L, S, H, D, gridtype, align_corners != 0);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("grid_encode_forward", s, B);
     const bool g = calc_grad_inputs != 0, ac = align_corners != 0;
@@ -330,7 +337,7 @@ int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* 
     NGP_REQUIRE(!(dtype == NGP_F16 && C == 1), "grid_encode_backward: fp16 with C == 1 is unsupported (grid.py:38 forces fp32 for odd C)");
     NGP_REQUIRE(!calc_grad_inputs || (dy_dx && grad_inputs), "grid_encode_backward: dy_dx/grad_inputs NULL but calc_grad_inputs set");
     GridLevels lv;
-    fill_levels(lv, offsets_host, L, S, H);
+    fill_levels(lv, offsets_host, L, S, H, D, gridtype, align_corners != 0);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("grid_encode_backward", s, B);
     const bool gi = calc_grad_inputs != 0, ac = align_corners != 0;

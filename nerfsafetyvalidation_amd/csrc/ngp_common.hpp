@@ -35,7 +35,31 @@ struct ProfScope {
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// ---- hash-grid level geometry, evaluated once per call on the host -----------------
+// scale / resolution exactly as gridencoder.cu:126-128; the index recipe of get_grid_index
+// (gridencoder.cu:54-72) is folded into per-level multipliers so that the device code does
+// no data-dependent loop:  index = hashed ? fast_hash(p) : p0 + p1*mul1 + p2*mul2, then
+// reduced modulo hashmap_size (mode 0: already < size, 1: size is a power of two, 2: generic %).
+constexpr int kMaxLevels = 32;
+struct GridLevels {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+    uint32_t offset[kMaxLevels + 1];
+    uint32_t mul1[kMaxLevels], mul2[kMaxLevels];
+    uint8_t hashed[kMaxLevels], mode[kMaxLevels];
+};
+void fill_levels(GridLevels& lv, const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t D, uint32_t gridtype,
+                 bool align_corners);
+
 // ---- device helpers ---------------------------------------------------------------
+// fp16(w * g) with the reference's two roundings (fp32 product, then fp16; c10::Half arithmetic,
+// gridencoder.cu:169-172).  The empty asm keeps hipcc from folding the multiply and the conversion
+// into v_fma_mixlo_f16, which rounds once and differs in rare tie cases.
+__device__ __forceinline__ _Float16 mul_round_f16(float w, _Float16 g) {
+    float p = w * (float)g;
+    asm volatile("" : "+v"(p));
+    return (_Float16)p;
+}
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 __device__ __forceinline__ float signf(float x) { return copysignf(1.0f, x); }
 

@@ -1,21 +1,755 @@
-// render_fused.hip -- placeholder entry points (replaced by the fused renderer).
+// render_fused.hip -- the MI355X-native body of NeRFRenderer.run_cuda (eval branch,
+// /root/reference/nerf/renderer.py:329-378): march -> hash-grid encode -> sigma MLP -> SH ->
+// colour MLP -> composite -> stable compaction, one fused kernel per reference loop iteration.
+//
+// What the reference does per iteration (6+ launches, 3 zero-filled [M,*] tensors, a host sync
+// for the boolean-mask compaction) becomes two launches and no host round trip:
+//
+//   k_render_iter   512-thread workgroups (8 waves).  A wave owns 64 alive rays:
+//     1. lane = ray: occupancy-grid DDA (ngp::Dda, bit-identical to march_rays) emits up to
+//        n_step sample parameters (t, dt) into the wave's LDS slab -- no [M,3] xyzs/dirs/deltas;
+//     2. the wave's valid samples are compacted (wave prefix sum) and processed 16 at a time:
+//        lane = (sample c = lane & 15, quarter q = lane >> 4).  Each lane gathers 4 of the 16
+//        hash levels (q, q+4, q+8, q+12; 32 four-byte table reads in flight per lane) and
+//        interpolates them with the reference's fp16 rounding sequence.  Its 8 features ARE the
+//        B fragment of v_mfma_f32_16x16x32_f16 for the TRANSPOSED product H^T = W * X^T, so
+//        the encoder output never touches memory.  Every following layer consumes the previous
+//        accumulator directly as its B fragment (the k-order permutation this implies is folded
+//        into the weight fragments once, by k_pack_weights); activations never leave registers.
+//        Weights live in LDS as ready-made A fragments (16 B per lane, conflict-free b128 reads).
+//     3. lane = ray again: composite_rays arithmetic on the wave's LDS results, state update,
+//        survivor ballot -> block-local stable compaction into a staging list.
+//   k_render_compact  stitches the per-group survivor lists into the next alive list (stable,
+//        = rays_alive[rays_alive >= 0]) and evaluates the reference's schedule on the device:
+//        n_step = clamp(N // n_alive, 1, 8), step += n_step, stop when step >= max_steps.
+//
+// The host enqueues iterations ahead of the device-side state (kernels read n_alive / n_step from
+// device memory and return immediately once `done` is set) and learns the state through a pinned
+// status ring, so the stream never drains while the host catches up.
+//
+// Numerics: identical expressions to the operator kernels (explicit fmaf, -ffp-contract=off).
+#include <hip/hip_fp16.h>
+#include <math.h>
+
 #include "ngp_common.hpp"
+
+namespace ngp {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 8;                 // waves per workgroup
+constexpr int kThreads = kWaves * 64;     // 512
+constexpr int kGroup = kThreads;          // alive-list entries handled per workgroup pass
+constexpr int kMaxStep = 8;               // reference: n_step <= 8
+constexpr int kSlots = 64 * kMaxStep;     // sample slots per wave
+constexpr int kLookahead = 4;             // iterations the host may enqueue beyond the last status it has seen
+constexpr int kRing = 8;
+
+// device-side loop state (ping-pong pair); also the pinned status record
+struct Ctl {
+    uint32_t n_alive, n_step, step, done;
+    uint32_t iters, last_n_alive, last_n_step, pad;
+    unsigned long long samples_marched, samples_slots;
+};
+
+// per-level table staged in LDS (16 levels)
+struct LevelTab {
+    float scale[16];
+    uint32_t offset[16], size[16], mul1[16], mul2[16];
+    uint32_t flags[16];  // bit0 hashed, bits 1-2 mode
+};
+
+struct NetArgs {
+    const uint32_t* table;     // fp16 pairs viewed as u32
+    const _Float16* packed;    // fragment-major weights (global)
+    uint32_t sig_mm, col_mm;   // hidden->hidden matmuls
+    float bound, two_bound, density_scale;
+    int align_corners;
+};
+
+__host__ __device__ inline uint32_t sig_halfs(uint32_t mm) { return 2048 + mm * 4096 + 1024; }
+
+// ------------------------------------------------------------------------------------------
+// weight fragment packing.  Source blobs are FFMLP-layout [64 x 32 | mm x 64 x 64 | 16 x 64].
+// Destination: for every (layer, 16-row block ob, 32-wide k step s, lane) 8 halfs = the lane's
+// A fragment for v_mfma_f32_16x16x32_f16 (row = 16*ob + (lane & 15), k index permuted):
+//   first sigma layer : k(q, j) = 2*(q + 4*(j >> 1)) + (j & 1)      (lane q gathers levels q, q+4, q+8, q+12)
+//   first colour layer: k(q, j) = j < 4 ? 4q + j                      (SH 4q..4q+3)
+//                                : (q == 0 && j == 4) ? 31           (the zero pad feature sits where lane 0 holds sigma)
+//                                : 15 + 4q + (j - 4)                  (geo_feat = sigma-net outputs 4q..4q+3, shifted by 15)
+//   hidden / output   : k(q, j, s) = 32 s + 16*(j >> 2) + 4q + (j & 3)  (accumulators of row blocks 2s, 2s+1)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t perm_grid(uint32_t q, uint32_t j) { return 2 * (q + 4 * (j >> 1)) + (j & 1); }
+__device__ __forceinline__ uint32_t perm_color(uint32_t q, uint32_t j) {
+    return j < 4 ? 4 * q + j : ((q == 0 && j == 4) ? 31u : 15 + 4 * q + (j - 4));
+}
+__device__ __forceinline__ uint32_t perm_hidden(uint32_t q, uint32_t j, uint32_t s) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
+
+__global__ void k_pack_weights(const _Float16* __restrict__ sig, uint32_t sig_mm, const _Float16* __restrict__ col, uint32_t col_mm,
+                               _Float16* __restrict__ packed) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_sig = sig_halfs(sig_mm), n_col = sig_halfs(col_mm);
+    if (e >= n_sig + n_col) return;
+    const bool is_col = e >= n_sig;
+    const uint32_t r = is_col ? e - n_sig : e;
+    const uint32_t mm = is_col ? col_mm : sig_mm;
+    const _Float16* src = is_col ? col : sig;
+    const uint32_t j = r & 7, lane = (r >> 3) & 63, c = lane & 15, q = lane >> 4;
+    uint32_t src_idx;
+    if (r < 2048) {                                   // input layer [ob][lane][8]
+        const uint32_t ob = r >> 9;
+        const uint32_t k = is_col ? perm_color(q, j) : perm_grid(q, j);
+        src_idx = (16 * ob + c) * 32 + k;
+    } else if (r < 2048 + mm * 4096) {                // hidden layers [k][ob][s][lane][8]
+        const uint32_t rr = r - 2048, layer = rr >> 12, in = rr & 4095;
+        const uint32_t ob = in >> 10, s = (in >> 9) & 1;
+        src_idx = 2048 + layer * 4096 + (16 * ob + c) * 64 + perm_hidden(q, j, s);
+    } else {                                          // output layer [s][lane][8]
+        const uint32_t in = r - 2048 - mm * 4096, s = in >> 9;
+        src_idx = 2048 + mm * 4096 + c * 64 + perm_hidden(q, j, s);
+    }
+    packed[e] = src[src_idx];
+}
+
+// ------------------------------------------------------------------------------------------
+// the network on one 16-sample tile.  All 64 lanes participate; lane = (c = sample, q = quarter).
+// Returns in lanes with q == 0: sigma (trunc_exp output, unscaled) and rgb (fp16-rounded sigmoid).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ half8 relu_pack(const f32x4& a, const f32x4& b) {
+    half8 h;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const _Float16 x = (_Float16)a[r], y = (_Float16)b[r];
+        h[r] = x > (_Float16)0 ? x : (_Float16)0;
+        h[4 + r] = y > (_Float16)0 ? y : (_Float16)0;
+    }
+    return h;
+}
+
+__device__ __forceinline__ void mlp_in(const half8* W, uint32_t lane, half8 x, half8 (&h)[2]) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[ob * 64 + lane], x, (f32x4){0, 0, 0, 0}, 0, 0, 0);
+    h[0] = relu_pack(acc[0], acc[1]);
+    h[1] = relu_pack(acc[2], acc[3]);
+}
+__device__ __forceinline__ void mlp_hidden(const half8* W, uint32_t lane, half8 (&h)[2]) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) {
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(ob * 2 + 0) * 64 + lane], h[0], (f32x4){0, 0, 0, 0}, 0, 0, 0);
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[(ob * 2 + 1) * 64 + lane], h[1], acc[ob], 0, 0, 0);
+    }
+    h[0] = relu_pack(acc[0], acc[1]);
+    h[1] = relu_pack(acc[2], acc[3]);
+}
+__device__ __forceinline__ f32x4 mlp_out(const half8* W, uint32_t lane, const half8 (&h)[2]) {
+    f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[lane], h[0], (f32x4){0, 0, 0, 0}, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(W[64 + lane], h[1], o, 0, 0, 0);
+}
+
+// degree-4 real SH of a direction, the 4 values index 4q..4q+3 (shencoder.cu:51-70 as products, see shencoder.hip)
+__device__ __forceinline__ void sh4_quarter(uint32_t q, float x, float y, float z, float (&o)[4]) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    if (q == 0) {
+        o[0] = 0.28209479177387814f;
+        o[1] = -0.48860251190291987f * y;
+        o[2] = 0.48860251190291987f * z;
+        o[3] = -0.48860251190291987f * x;
+    } else if (q == 1) {
+        o[0] = 1.0925484305920792f * xy;
+        o[1] = -1.0925484305920792f * yz;
+        o[2] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+        o[3] = -1.0925484305920792f * xz;
+    } else if (q == 2) {
+        o[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+        o[1] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+        o[2] = 2.8906114426405538f * xy * z;
+        o[3] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    } else {
+        o[0] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+        o[1] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+        o[2] = 1.4453057213202769f * z * (x2 - y2);
+        o[3] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    }
+}
+
+__device__ __forceinline__ uint32_t level_index(const LevelTab& lt, uint32_t level, uint32_t p0, uint32_t p1, uint32_t p2) {
+    const uint32_t fl = lt.flags[level];
+    uint32_t idx = (fl & 1u) ? (p0 ^ (p1 * 2654435761u) ^ (p2 * 805459861u)) : p0 + p1 * lt.mul1[level] + p2 * lt.mul2[level];
+    const uint32_t mode = fl >> 1;
+    if (mode == 1) idx &= lt.size[level] - 1;
+    else if (mode == 2) idx %= lt.size[level];
+    return idx;
+}
+
+__device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
+                                         float dx, float dy, float dz, float& sigma, float& cr, float& cg, float& cb) {
+    const uint32_t q = lane >> 4;
+    // encoder input: (x + bound) / (2 bound)  (gridencoder/grid.py:144)
+    const float u0 = (x + na.bound) / na.two_bound, u1 = (y + na.bound) / na.two_bound, u2 = (z + na.bound) / na.two_bound;
+    const bool oob = (u0 < 0 || u0 > 1) || (u1 < 0 || u1 > 1) || (u2 < 0 || u2 > 1);
+    const float half_off = na.align_corners ? 0.0f : 0.5f;
+
+    // ---- 4 levels x 8 corners: issue all 32 gathers, then interpolate (gridencoder.cu:139-175)
+    uint32_t raw[4][8];
+    float fr[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t level = q + 4 * i;
+        const float scale = lt.scale[level];
+        float p[3] = {fmaf(u0, scale, half_off), fmaf(u1, scale, half_off), fmaf(u2, scale, half_off)};
+        uint32_t g[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float fl = floorf(p[d]);
+            g[d] = (uint32_t)fl;
+            fr[i][d] = p[d] - (float)g[d];
+        }
+        const uint32_t* tab = na.table + lt.offset[level];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const uint32_t e = level_index(lt, level, g[0] + (idx & 1), g[1] + ((idx >> 1) & 1), g[2] + ((idx >> 2) & 1));
+            raw[i][idx] = oob ? 0u : tab[e];
+        }
+    }
+    half8 feat;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        _Float16 a0 = (_Float16)0, a1 = (_Float16)0;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            float w = 1;
+            w *= (idx & 1) ? fr[i][0] : 1 - fr[i][0];
+            w *= (idx & 2) ? fr[i][1] : 1 - fr[i][1];
+            w *= (idx & 4) ? fr[i][2] : 1 - fr[i][2];
+            const half2v g = __builtin_bit_cast(half2v, raw[i][idx]);
+            a0 = a0 + mul_round_f16(w, g[0]);
+            a1 = a1 + mul_round_f16(w, g[1]);
+        }
+        feat[2 * i] = oob ? (_Float16)0 : a0;
+        feat[2 * i + 1] = oob ? (_Float16)0 : a1;
+    }
+
+    // ---- sigma net: 32 -> 64 (-> 64)* -> 16
+    const half8* Ws = reinterpret_cast<const half8*>(Wlds);
+    half8 h[2];
+    mlp_in(Ws, lane, feat, h);
+    for (uint32_t k = 0; k < na.sig_mm; k++) mlp_hidden(Ws + 256 + k * 512, lane, h);
+    const f32x4 so = mlp_out(Ws + 256 + na.sig_mm * 512, lane, h);
+    _Float16 s16[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) s16[r] = (_Float16)so[r];
+    sigma = expf((float)s16[0]);  // trunc_exp forward (activation.py:8-10), meaningful in q == 0
+
+    // ---- colour net input: [SH(16) | geo_feat(15) | 0] in the permuted k order of perm_color
+    float sh[4];
+    sh4_quarter(q, dx, dy, dz, sh);
+    half8 cin;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        cin[r] = (_Float16)sh[r];
+        cin[4 + r] = s16[r];
+    }
+    if (q == 0) cin[4] = (_Float16)0;  // lane 0's accumulator row 0 is sigma, not a feature: this slot carries the zero pad
+    const half8* Wc = reinterpret_cast<const half8*>(Wlds + sig_halfs(na.sig_mm));
+    mlp_in(Wc, lane, cin, h);
+    for (uint32_t k = 0; k < na.col_mm; k++) mlp_hidden(Wc + 256 + k * 512, lane, h);
+    const f32x4 co = mlp_out(Wc + 256 + na.col_mm * 512, lane, h);
+    // torch.sigmoid on a half tensor: evaluate in fp32, round to fp16
+    cr = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[0])));
+    cg = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[1])));
+    cb = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[2])));
+}
+
+// stage packed weights + level table into LDS (all threads of the block)
+__device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels& lv, _Float16* Wlds, LevelTab* lt) {
+    const uint32_t n16 = (sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) / 8;  // 16-byte chunks
+    const uint4* src = reinterpret_cast<const uint4*>(na.packed);
+    uint4* dst = reinterpret_cast<uint4*>(Wlds);
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < 16) {
+        const uint32_t l = threadIdx.x;
+        lt->scale[l] = lv.scale[l];
+        lt->offset[l] = lv.offset[l];
+        lt->size[l] = lv.offset[l + 1] - lv.offset[l];
+        lt->mul1[l] = lv.mul1[l];
+        lt->mul2[l] = lv.mul2[l];
+        lt->flags[l] = (uint32_t)lv.hashed[l] | ((uint32_t)lv.mode[l] << 1);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// NeRFNetwork.forward on an explicit point list (network_ff.py:51-75)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels lv, const float* __restrict__ xyzs,
+                                                         const float* __restrict__ dirs, uint32_t M, float* __restrict__ sigmas,
+                                                         float* __restrict__ rgbs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_tiles = (M + 15) / 16;
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t m = tile * 16 + c;
+        const uint32_t mm = m < M ? m : M - 1;
+        float sg, r, g, b;
+        net_tile(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], dirs[(size_t)mm * 3],
+                 dirs[(size_t)mm * 3 + 1], dirs[(size_t)mm * 3 + 2], sg, r, g, b);
+        if (lane < 16 && m < M) {
+            sigmas[m] = sg;
+            rgbs[(size_t)m * 3] = r;
+            rgbs[(size_t)m * 3 + 1] = g;
+            rgbs[(size_t)m * 3 + 2] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// render iteration
+// ------------------------------------------------------------------------------------------
+struct RenderArgs {
+    const float *rays_o, *rays_d, *fars;
+    float* rays_t;
+    float *weights_sum, *depth, *image;
+    float *last_sigmas, *last_rgbs;   // optional dump of the iteration's slot-major outputs
+    float pad_sigma, pad_r, pad_g, pad_b;
+    const int32_t* alive_in;
+    int32_t* staging;                 // [groups*kGroup] block-local compacted survivors
+    uint32_t* group_count;            // [groups]
+    Ctl* ctl;                         // state read by this iteration
+    const uint8_t* bitfield;
+    uint32_t cascade, grid_size, max_steps, perturb;
+    float dt_gamma;
+    Pcg32 rng;
+};
+
+struct WaveSlab {  // per-wave LDS
+    float t[kSlots], dt[kSlots], sig[kSlots];
+    uint32_t rg[kSlots], b[kSlots];
+    uint16_t list[kSlots];
+    float od[64][6];
+};
+
+__global__ void __launch_bounds__(kThreads) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
+    const Ctl ctl = *ra.ctl;
+    if (ctl.done) return;
+    const uint32_t n_alive = ctl.n_alive, n_step = ctl.n_step;
+    const uint32_t n_groups = (n_alive + kGroup - 1) / kGroup;
+    if (blockIdx.x >= n_groups) return;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
+    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(smem + w_bytes + sizeof(LevelTab));  // [kWaves]
+    WaveSlab* slabs = reinterpret_cast<WaveSlab*>(smem + w_bytes + sizeof(LevelTab) + 64);
+    stage_block(na, lv, Wlds, lt);
+
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15;
+    WaveSlab& S = slabs[wid];
+
+    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        const uint32_t entry = group * kGroup + wid * 64 + lane;
+        const bool active = entry < n_alive;
+        const int32_t ray = active ? ra.alive_in[entry] : -1;
+
+        // ---- 1. march (raymarching.cu:706-814), lane = ray
+        uint32_t cnt = 0;
+        float t0 = 0, tp = 0;
+        if (active) {
+            Dda dda;
+            dda.init(ra.rays_o + (size_t)ray * 3, ra.rays_d + (size_t)ray * 3, ra.bitfield, na.bound, ra.dt_gamma, ra.max_steps, ra.cascade,
+                     ra.grid_size);
+            t0 = ra.rays_t[ray];
+            const float far = ra.fars[ray];
+            float t = t0;
+            if (ra.perturb) {
+                Pcg32 rng = ra.rng;
+                rng.advance((int64_t)entry);
+                t += dda.dt_min * rng.next_float();
+            }
+            tp = t;
+            float x, y, z, dt;
+            while (t < far && cnt < n_step) {
+                if (dda.probe(t, x, y, z, dt)) {
+                    S.t[lane * n_step + cnt] = t;
+                    S.dt[lane * n_step + cnt] = dt;
+                    t += dt;
+                    cnt++;
+                }
+            }
+            S.od[lane][0] = dda.ox; S.od[lane][1] = dda.oy; S.od[lane][2] = dda.oz;
+            S.od[lane][3] = dda.dx; S.od[lane][4] = dda.dy; S.od[lane][5] = dda.dz;
+        }
+        // ---- 2. compact the wave's samples and run the network 16 at a time
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += o;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        for (uint32_t k = 0; k < cnt; k++) S.list[incl - cnt + k] = (uint16_t)((lane << 3) | k);
+        // (single wave: LDS writes above are visible to the wave's later reads after the implicit waitcnt)
+        const uint32_t n_tiles = (total + 15) / 16;
+        for (uint32_t tile = 0; tile < n_tiles; tile++) {
+            const uint32_t j = tile * 16 + c;
+            const bool valid = j < total;
+            const uint32_t e = S.list[valid ? j : total - 1];
+            const uint32_t rl = e >> 3, slot = rl * n_step + (e & 7);
+            const float t = S.t[slot];
+            const float ox = S.od[rl][0], oy = S.od[rl][1], oz = S.od[rl][2];
+            const float dx = S.od[rl][3], dy = S.od[rl][4], dz = S.od[rl][5];
+            const float x = clampf(fmaf(t, dx, ox), -na.bound, na.bound);
+            const float y = clampf(fmaf(t, dy, oy), -na.bound, na.bound);
+            const float z = clampf(fmaf(t, dz, oz), -na.bound, na.bound);
+            float sg, r, g, b;
+            net_tile(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
+            if (lane < 16 && valid) {
+                S.sig[slot] = na.density_scale * sg;   // renderer.py:365
+                S.rg[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)r) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)g) << 16);
+                S.b[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b);
+            }
+        }
+        // ---- 3. composite (raymarching.cu:828-913), lane = ray
+        bool survive = false;
+        if (active) {
+            float t = t0, last_t = tp;
+            float ws = ra.weights_sum[ray], d = ra.depth[ray];
+            float r = ra.image[(size_t)ray * 3], g = ra.image[(size_t)ray * 3 + 1], b = ra.image[(size_t)ray * 3 + 2];
+            uint32_t step = 0;
+            while (step < n_step) {
+                if (step >= cnt) break;  // deltas[0] == 0: the march ran out of samples
+                const uint32_t slot = lane * n_step + step;
+                const float dt = S.dt[slot];
+                const float t_after = S.t[slot] + dt;
+                const float delta1 = t_after - last_t;
+                last_t = t_after;
+                const float sg = S.sig[slot];
+                const uint32_t rg = S.rg[slot];
+                const float cr = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg & 0xffffu));
+                const float cg = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg >> 16));
+                const float cb = (float)__builtin_bit_cast(_Float16, (uint16_t)(S.b[slot] & 0xffffu));
+                const float alpha = 1.0f - expf(-sg * dt);
+                const float T = 1 - ws;
+                const float w = alpha * T;
+                ws += w;
+                t += delta1;
+                d = fmaf(w, t, d);
+                r = fmaf(w, cr, r); g = fmaf(w, cg, g); b = fmaf(w, cb, b);
+                if ((double)T < 1e-4) break;
+                step++;
+            }
+            survive = step == n_step;
+            if (survive) ra.rays_t[ray] = t;
+            ra.weights_sum[ray] = ws; ra.depth[ray] = d;
+            ra.image[(size_t)ray * 3] = r; ra.image[(size_t)ray * 3 + 1] = g; ra.image[(size_t)ray * 3 + 2] = b;
+            if (ra.last_sigmas) {
+                for (uint32_t k = 0; k < n_step; k++) {
+                    const size_t row = (size_t)entry * n_step + k;
+                    const uint32_t slot = lane * n_step + k;
+                    const bool have = k < cnt;
+                    ra.last_sigmas[row] = have ? S.sig[slot] : ra.pad_sigma;
+                    ra.last_rgbs[row * 3] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.rg[slot] & 0xffffu)) : ra.pad_r;
+                    ra.last_rgbs[row * 3 + 1] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.rg[slot] >> 16)) : ra.pad_g;
+                    ra.last_rgbs[row * 3 + 2] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.b[slot] & 0xffffu)) : ra.pad_b;
+                }
+            }
+        }
+        // ---- 4. stable block-local compaction of survivors
+        const unsigned long long ball = __ballot(survive);
+        const uint32_t wave_surv = (uint32_t)__popcll(ball);
+        const uint32_t rank_in_wave = (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+        if (lane == 0) {
+            wave_cnt[wid] = wave_surv;
+            if (total) atomicAdd(&ra.ctl->samples_marched, (unsigned long long)total);
+        }
+        __syncthreads();
+        uint32_t base = 0, block_total = 0;
+        for (uint32_t w = 0; w < (uint32_t)kWaves; w++) {
+            const uint32_t v = wave_cnt[w];
+            if (w < wid) base += v;
+            block_total += v;
+        }
+        if (survive) ra.staging[(size_t)group * kGroup + base + rank_in_wave] = ray;
+        if (threadIdx.x == 0) ra.group_count[group] = block_total;
+        __syncthreads();  // wave_cnt is reused by the next group
+    }
+    // padding rows of the reference's [M_padded] tensors (M += 128 - M % 128), written by the last group's block
+    if (ra.last_sigmas && blockIdx.x == (n_groups - 1) % gridDim.x && threadIdx.x < 128) {
+        const size_t row = (size_t)n_alive * n_step + threadIdx.x;
+        ra.last_sigmas[row] = ra.pad_sigma;
+        ra.last_rgbs[row * 3] = ra.pad_r; ra.last_rgbs[row * 3 + 1] = ra.pad_g; ra.last_rgbs[row * 3 + 2] = ra.pad_b;
+    }
+}
+
+// stitch group survivor lists -> next alive list; advance the reference's schedule (renderer.py:347-373)
+__global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ cur, Ctl* __restrict__ nxt, const int32_t* __restrict__ staging,
+                                                         const uint32_t* __restrict__ group_count, int32_t* __restrict__ alive_out, uint32_t N,
+                                                         uint32_t max_steps) {
+    __shared__ uint32_t red[4];
+    const Ctl c = *cur;
+    if (c.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = c;
+        return;
+    }
+    const uint32_t n_groups = (c.n_alive + kGroup - 1) / kGroup;
+    const uint32_t g = blockIdx.x;
+    if (g >= n_groups) return;
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < g; j += 256) part += group_count[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const uint32_t prefix = red[0] + red[1] + red[2] + red[3];
+    const uint32_t mine = group_count[g];
+    for (uint32_t i = threadIdx.x; i < mine; i += 256) alive_out[prefix + i] = staging[(size_t)g * kGroup + i];
+    if (g == n_groups - 1 && threadIdx.x == 0) {
+        Ctl n = c;
+        n.last_n_alive = c.n_alive;
+        n.last_n_step = c.n_step;
+        n.iters = c.iters + 1;
+        n.samples_slots = c.samples_slots + (unsigned long long)c.n_alive * c.n_step;
+        n.step = c.step + c.n_step;
+        n.n_alive = prefix + mine;
+        uint32_t ns = n.n_alive ? N / n.n_alive : 8;
+        n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
+        n.done = (n.n_alive == 0 || n.step >= max_steps) ? 1 : 0;
+        *nxt = n;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __restrict__ nears, float* __restrict__ rays_t,
+                                                      int32_t* __restrict__ alive, float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                      float* __restrict__ image, Ctl* __restrict__ ctl, uint32_t max_steps) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) {
+        alive[n] = (int32_t)n;
+        rays_t[n] = nears[n];
+        weights_sum[n] = 0; depth[n] = 0;
+        image[(size_t)n * 3] = 0; image[(size_t)n * 3 + 1] = 0; image[(size_t)n * 3 + 2] = 0;
+    }
+    if (n == 0) {
+        Ctl c = {};
+        c.n_alive = N;
+        c.n_step = 1;  // clamp(N // N, 1, 8)
+        c.done = (N == 0 || max_steps == 0) ? 1 : 0;
+        ctl[0] = c;
+        ctl[1] = c;
+    }
+}
+
+}  // namespace ngp
+
 using namespace ngp;
+
+struct ngp_render_ctx {
+    uint32_t max_rays = 0;
+    int32_t* alive[2] = {nullptr, nullptr};
+    int32_t* staging = nullptr;
+    uint32_t* group_count = nullptr;
+    float* rays_t = nullptr;
+    Ctl* ctl = nullptr;          // device [2]
+    _Float16* packed = nullptr;  // device
+    Ctl* status = nullptr;       // pinned [kRing]
+    hipEvent_t ev[kRing];
+    int num_cu = 256;
+};
+
+static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
+    NGP_REQUIRE(m && m->embeddings && m->offsets_host && m->sigma_weights && m->color_weights, "ngp_model: null pointer");
+    NGP_REQUIRE(m->L == 16, "fused renderer: the hash grid must have 16 levels with 2 features (got L=%u)", m->L);
+    NGP_REQUIRE(m->sigma_hidden_mm <= 2 && m->color_hidden_mm <= 3, "fused renderer: at most 2 / 3 hidden matmuls (got %u / %u)",
+                m->sigma_hidden_mm, m->color_hidden_mm);
+    (void)ctx;
+    fill_levels(lv, m->offsets_host, 16, m->S, m->H_base, 3, m->gridtype, m->align_corners != 0);
+    na.table = reinterpret_cast<const uint32_t*>(m->embeddings);
+    na.packed = packed;
+    na.sig_mm = m->sigma_hidden_mm;
+    na.col_mm = m->color_hidden_mm;
+    na.bound = m->bound;
+    na.two_bound = 2 * m->bound;
+    na.density_scale = m->density_scale;
+    na.align_corners = m->align_corners;
+    return NGP_OK;
+}
+
+static size_t weights_bytes(const NetArgs& na) { return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2; }
+
 extern "C" {
-int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) { (void)max_rays; (void)out; set_error("render_ctx_create: not built"); return NGP_EINVAL; }
-int ngp_render_ctx_destroy(ngp_render_ctx* ctx) { (void)ctx; return NGP_OK; }
+
+int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
+    NGP_REQUIRE(out, "render_ctx_create: null out pointer");
+    NGP_REQUIRE(max_rays > 0, "render_ctx_create: max_rays must be positive");
+    ngp_render_ctx* c = new ngp_render_ctx();
+    c->max_rays = max_rays;
+    const size_t groups = div_up(max_rays, kGroup);
+    bool ok = true;
+    ok &= hipMalloc(&c->alive[0], (size_t)max_rays * 4) == hipSuccess;
+    ok &= hipMalloc(&c->alive[1], (size_t)max_rays * 4) == hipSuccess;
+    ok &= hipMalloc(&c->staging, groups * kGroup * 4) == hipSuccess;
+    ok &= hipMalloc(&c->group_count, groups * 4) == hipSuccess;
+    ok &= hipMalloc(&c->rays_t, (size_t)max_rays * 4) == hipSuccess;
+    ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
+    ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
+    ok &= hipHostMalloc(&c->status, kRing * sizeof(Ctl), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; i < kRing; i++) ok &= hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (!ok) {
+        set_error("render_ctx_create: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        ngp_render_ctx_destroy(c);
+        return NGP_ENODEVICE;
+    }
+    *out = c;
+    return NGP_OK;
+}
+
+int ngp_render_ctx_destroy(ngp_render_ctx* c) {
+    if (!c) return NGP_OK;
+    (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->group_count);
+    (void)hipFree(c->rays_t); (void)hipFree(c->ctl); (void)hipFree(c->packed);
+    if (c->status) (void)hipHostFree(c->status);
+    for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+    return NGP_OK;
+}
+
 int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears,
                     const float* fars, uint32_t N, float dt_gamma, uint32_t max_steps, uint32_t perturb, float* weights_sum, float* depth,
-                    float* image, ngp_render_stats* stats_host, int sync, ngp_stream_t stream) {
-    (void)ctx; (void)model; (void)rays_o; (void)rays_d; (void)nears; (void)fars; (void)N; (void)dt_gamma; (void)max_steps; (void)perturb;
-    (void)weights_sum; (void)depth; (void)image; (void)stats_host; (void)sync; (void)stream;
-    set_error("render_rays: not built");
-    return NGP_EINVAL;
+                    float* image, float* last_sigmas, float* last_rgbs, const float* pad_value_host, ngp_render_stats* stats_host, int sync,
+                    ngp_stream_t stream) {
+    NGP_REQUIRE(ctx, "render_rays: null context");
+    NGP_REQUIRE(N <= ctx->max_rays, "render_rays: %u rays exceed the context capacity %u", N, ctx->max_rays);
+    NGP_REQUIRE((last_sigmas == nullptr) == (last_rgbs == nullptr), "render_rays: last_sigmas and last_rgbs must both be given or both NULL");
+    if (stats_host) *stats_host = ngp_render_stats{};
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && nears && fars && weights_sum && depth && image, "render_rays: null pointer");
+    NGP_REQUIRE(model && model->density_bitfield, "render_rays: model has no density bitfield");
+    NGP_REQUIRE(model->cascade >= 1 && model->cascade <= 8 && model->grid_size >= 2 && model->grid_size <= 1024,
+                "render_rays: unsupported cascade/grid size");
+    hipStream_t s = (hipStream_t)stream;
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, ctx, ctx->packed, na, lv);
+    if (rc) return rc;
+
+    const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
+    k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
+                                                         (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
+    k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps);
+
+    RenderArgs ra = {};
+    ra.rays_o = rays_o; ra.rays_d = rays_d; ra.fars = fars; ra.rays_t = ctx->rays_t;
+    ra.weights_sum = weights_sum; ra.depth = depth; ra.image = image;
+    ra.last_sigmas = last_sigmas; ra.last_rgbs = last_rgbs;
+    if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
+    ra.staging = ctx->staging; ra.group_count = ctx->group_count;
+    ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
+    ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
+    ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
+
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab) + 64 + (size_t)kWaves * sizeof(WaveSlab);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    NGP_REQUIRE(lds <= 160 * 1024, "render_rays: LDS budget exceeded (%zu bytes)", lds);
+
+    uint32_t ub = N;          // host-side upper bound of n_alive
+    uint32_t launched = 0;    // iterations enqueued
+    uint32_t known = 0;       // iterations whose resulting status the host has read
+    uint32_t launches = 2;
+    bool done = false;
+    Ctl last = {};
+    ProfScope prof("render_rays", s, N);
+    while (!done) {
+        const uint32_t cur = launched & 1;
+        const uint32_t groups = div_up(ub ? ub : 1, kGroup);
+        const uint32_t blocks = groups < (uint32_t)ctx->num_cu ? groups : (uint32_t)ctx->num_cu;  // one 512-thread workgroup per CU
+        ra.alive_in = ctx->alive[cur];
+        ra.ctl = ctx->ctl + cur;
+        k_render_iter<<<blocks, kThreads, lds, s>>>(na, lv, ra);
+        k_render_compact<<<groups, 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->group_count, ctx->alive[cur ^ 1], N,
+                                                max_steps);
+        (void)hipMemcpyAsync(&ctx->status[launched % kRing], ctx->ctl + (cur ^ 1), sizeof(Ctl), hipMemcpyDeviceToHost, s);
+        (void)hipEventRecord(ctx->ev[launched % kRing], s);
+        launched++;
+        launches += 2;
+        // consume every status that has already landed; block only when too far ahead
+        while (known < launched) {
+            const bool must_wait = launched - known >= (uint32_t)kLookahead;
+            if (must_wait) (void)hipEventSynchronize(ctx->ev[known % kRing]);
+            else if (hipEventQuery(ctx->ev[known % kRing]) != hipSuccess) break;
+            last = ctx->status[known % kRing];
+            known++;
+            ub = last.n_alive;
+            if (last.done) { done = true; break; }
+        }
+        if (launched > max_steps + 8u) {  // cannot happen: every iteration advances step by >= 1
+            set_error("render_rays: iteration bound exceeded");
+            return NGP_ELAUNCH;
+        }
+    }
+    rc = check_launch("render_rays");
+    if (rc) return rc;
+    if (stats_host || sync) {
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
+            return NGP_ELAUNCH;
+        }
+        if (stats_host) {
+            const Ctl fin = ctx->status[(launched - 1) % kRing];  // state after the last enqueued iteration (done is sticky)
+            stats_host->samples_marched = fin.samples_marched;
+            stats_host->samples_slots = fin.samples_slots;
+            stats_host->iterations = fin.iters;
+            stats_host->rays = N;
+            stats_host->last_n_alive = fin.last_n_alive;
+            stats_host->last_n_step = fin.last_n_step;
+            stats_host->launches = launches;
+        }
+    }
+    return NGP_OK;
 }
+
 int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, float* rgbs,
                         ngp_stream_t stream) {
-    (void)model; (void)xyzs; (void)dirs; (void)M; (void)sigmas; (void)rgbs; (void)stream;
-    set_error("network_forward: not built");
-    return NGP_EINVAL;
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(xyzs && dirs && sigmas && rgbs, "network_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    static _Float16* packed = nullptr;  // setup-time scratch, one per process
+    if (!packed && hipMalloc(&packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) != hipSuccess) {
+        set_error("network_forward: hipMalloc failed");
+        return NGP_ENODEVICE;
+    }
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, nullptr, packed, na, lv);
+    if (rc) return rc;
+    const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
+    k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
+                                                         (const _Float16*)model->color_weights, na.col_mm, packed);
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    const uint32_t n_tiles = div_up(M, 16);
+    uint32_t blocks = div_up(n_tiles, 4);
+    if (blocks > 1024) blocks = 1024;
+    ProfScope prof("network_forward", s, M);
+    k_network_forward<<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    return check_launch("network_forward");
 }
-}
+
+}  // extern "C"

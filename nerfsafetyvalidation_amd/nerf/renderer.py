@@ -230,7 +230,8 @@ class NeRFRenderer(nn.Module):
         else:
             fm = self.fused_model() if self.fused else None
             if fm is not None and not torch.is_grad_enabled():
-                weights_sum, depth, image, sigmas, rgbs = fm.render(rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb)
+                weights_sum, depth, image, sigmas, rgbs = fm.render(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb)
+                self.last_render_stats = fm.last_stats
             else:
                 weights_sum, depth, image, sigmas, rgbs = self._march_composite_loop(rays_o, rays_d, nears, fars, dt_gamma,
                                                                                      max_steps, perturb)
