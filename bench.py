@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered samples/s and frames/s of the Instant-NGP render path on MI355X.
+
+Workload (BASELINE.json configs[1]): Stonehenge 800x800, hashgrid L=16 F=2 + ffmlp(64,2), fp16, occupancy-grid
+ray marching, one full frame per step through NeRFNetwork.render (get_rays -> near/far -> fused march/encode/
+MLP/composite loop -> background mix).  Poses, model and occupancy are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One JSON line on rank 0; fields per the driver contract plus `roofline` (dominant kernel, HIP-event timed in a
+separate profiled pass) and `cpu_baseline` (the CPU oracle on a bounded sample of the same frame, rank 0, N = 1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+TABLE_BYTES_PER_SAMPLE = 16 * 8 * 4          # 16 levels x 8 corners x (2 x fp16): SURVEY 8d, the fused design's floor
+RAY_BYTES_PER_RAY_ITER = 4 + 24 + 8 + 2 * 20  # alive id + o,d + t,far + read-modify-write of (weights_sum, depth, rgb)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--size", type=int, default=800, help="frame edge (800 = the named workload)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-stride", type=int, default=16, help="cpu_baseline renders rays[::stride] of view 0")
+    p.add_argument("--profile-steps", type=int, default=3)
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from nerfsafetyvalidation_amd import _lib
+    from nerfsafetyvalidation_amd.dist import gather_views
+    from nerfsafetyvalidation_amd.nerf.utils import get_rays
+    from nerfsafetyvalidation_amd.scene import StonehengeScene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    lib = _lib.lib()
+
+    H = W = args.size
+    sc = StonehengeScene(H=H, W=W, bound=2)
+    model = sc.build_model(dev)              # FFMLP backbone, cuda_ray=True, fused path on
+    poses = torch.from_numpy(sc.poses).to(dev)
+    n_views = poses.shape[0]
+    intr = sc.intrinsics
+
+    def view_of(step):                       # weak scaling: every rank renders its own camera each step
+        return (step * world + rank) % n_views
+
+    def render_step(step):
+        v = view_of(step)
+        rays = get_rays(poses[v:v + 1], intr, H, W)
+        out = model.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False)
+        st = model.last_render_stats
+        if world > 1:                        # the path's one exchange step: all-gather the rendered tiles
+            gather_views(out["image"], world)
+            gather_views(out["depth"], world)
+        return st["samples_marched"], st["iterations"], st["samples_slots"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        for i in range(args.warmup):
+            render_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        samples = iters = slots = 0
+        for i in range(args.steps):
+            s, it, sl = render_step(args.warmup + i)
+            samples += s
+            iters += it
+            slots += sl
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # ---- roofline leg: per-launch HIP events around the dominant kernel (k_render_iter), separate pass
+        roof = None
+        if rank == 0:
+            lib.ngp_prof_reset()
+            lib.ngp_prof_enable(1)
+            ray_iters = 0
+            for i in range(args.profile_steps):
+                render_step(args.warmup + i)
+                ray_iters += model.last_render_stats["samples_slots"]  # sum over iterations of n_alive * n_step
+            torch.cuda.synchronize()
+            lib.ngp_prof_enable(0)
+            ms, n_launch, units = C.c_double(), C.c_uint64(), C.c_double()
+            _lib.check(lib.ngp_prof_read(b"k_render_iter", C.byref(ms), C.byref(n_launch), C.byref(units)), "prof_read")
+            if n_launch.value:
+                algo_bytes = units.value * TABLE_BYTES_PER_SAMPLE + ray_iters * RAY_BYTES_PER_RAY_ITER
+                achieved = algo_bytes / (ms.value * 1e-3) / 1e9
+                roof = {"kernel": "k_render_iter (fused march+hashgrid+MLPs+composite)", "bound": "hbm",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
+                        "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
+                        "algorithmic_bytes_per_sample": TABLE_BYTES_PER_SAMPLE, "algorithmic_bytes_per_ray_iteration": RAY_BYTES_PER_RAY_ITER}
+
+    tot = torch.tensor([float(samples), float(iters), elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[2])
+    total_samples = float(tot[0])
+
+    # ---- cpu baseline leg: the oracle on a bounded sample of view 0 (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import driver as D
+        from oracle import oracle as O
+        ro, rd = D.pinhole_rays(sc.poses[view_of(0)], intr, H, W)
+        ro, rd = np.ascontiguousarray(ro[::args.cpu_stride]), np.ascontiguousarray(rd[::args.cpu_stride])
+        net = D.OracleNetwork.from_torch(model)
+        bitfield = sc.bitfield()
+        t1 = time.perf_counter()
+        res = D.oracle_run_cuda(net, ro, rd, bitfield, sc.bound, sc.cascade, sc.density_scale)
+        cpu_t = time.perf_counter() - t1
+        cpu = {"value": round(res["samples_marched"] / cpu_t, 1), "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
+               "sample": f"rays[::{args.cpu_stride}] of view {view_of(0)} ({ro.shape[0]} of {H * W} rays, {res['samples_marched']} samples, "
+                         f"{cpu_t:.1f} s): oracle/ngp_oracle.c (OpenMP) driven by the reference's run_cuda loop"}
+
+    if rank == 0:
+        frames = args.steps * world
+        line = {
+            "metric": "rendered_samples_per_sec",
+            "value": round(total_samples / elapsed, 1),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"Stonehenge {H}x{W} synthetic, hashgrid L=16 F=2 T=2^19 + ffmlp(64,2)/(64,3), fp16, "
+                                   "occupancy-grid ray marching (run_cuda eval path, BASELINE configs[1])",
+                       "rays_per_frame": H * W, "bound": sc.bound, "cascade": sc.cascade, "density_scale": sc.density_scale,
+                       "parallelism": f"camera-sharded x{world}, RCCL all_gather of rendered tiles" if world > 1 else "single GPU"},
+            "frames_per_sec": round(frames / elapsed, 3),
+            "rays_per_sec": round(frames * H * W / elapsed, 1),
+            "samples_per_frame": round(total_samples / frames, 1),
+            "loop_iterations_per_frame": round(float(tot[1]) / frames, 1),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

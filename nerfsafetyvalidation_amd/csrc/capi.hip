@@ -64,6 +64,13 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(g_prof[slot].events.back().second, stream);
 }
 
+bool prof_enabled() { return g_prof_on; }
+void prof_add_units(const char* name, double units) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[prof_slot(name)].units += units;
+}
+
 static void prof_collect(ProfEntry& e) {
     for (auto& p : e.events) {
         (void)hipEventSynchronize(p.second);

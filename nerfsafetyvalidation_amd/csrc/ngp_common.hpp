@@ -32,6 +32,8 @@ struct ProfScope {
     int slot;
     hipStream_t stream;
 };
+bool prof_enabled();
+void prof_add_units(const char* name, double units);
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 

@@ -671,14 +671,16 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     uint32_t launches = 2;
     bool done = false;
     Ctl last = {};
-    ProfScope prof("render_rays", s, N);
     while (!done) {
         const uint32_t cur = launched & 1;
         const uint32_t groups = div_up(ub ? ub : 1, kGroup);
         const uint32_t blocks = groups < (uint32_t)ctx->num_cu ? groups : (uint32_t)ctx->num_cu;  // one 512-thread workgroup per CU
         ra.alive_in = ctx->alive[cur];
         ra.ctl = ctx->ctl + cur;
-        k_render_iter<<<blocks, kThreads, lds, s>>>(na, lv, ra);
+        {
+            ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
+            k_render_iter<<<blocks, kThreads, lds, s>>>(na, lv, ra);
+        }
         k_render_compact<<<groups, 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->group_count, ctx->alive[cur ^ 1], N,
                                                 max_steps);
         (void)hipMemcpyAsync(&ctx->status[launched % kRing], ctx->ctl + (cur ^ 1), sizeof(Ctl), hipMemcpyDeviceToHost, s);
@@ -716,6 +718,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             stats_host->last_n_alive = fin.last_n_alive;
             stats_host->last_n_step = fin.last_n_step;
             stats_host->launches = launches;
+            prof_add_units("k_render_iter", (double)fin.samples_marched);
         }
     }
     return NGP_OK;

@@ -1,0 +1,54 @@
+"""Camera-sharded rendering across the GPUs of one node.
+
+The model is small and read-only at inference (25 MB table + <40 KB weights + 0.5 MB bitfield): every rank
+holds a replica, the camera set is partitioned, and the only collective is ONE all_gather of the rendered
+tiles per sweep (torch.distributed backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+The reference's own (never-executed) collective use is the per-image all_gather of Trainer.evaluate_one_epoch
+(nerf/utils.py:872-882); there is no gradient traffic on this path.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world_size):
+    """contiguous block partition: [lo, hi) of rank; the first (n_items % world_size) ranks get one extra item"""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rows(H, rank, world_size, strip=8):
+    """row-strip interleave for sharding ONE frame: strip s -> rank s % world_size (occupancy makes tile cost uneven)"""
+    return [r for r in range(H) if (r // strip) % world_size == rank]
+
+
+def gather_views(local, n_total, group=None):
+    """all_gather of per-rank stacks of rendered views.  local: [n_local, ...] (n_local may differ by one between ranks).
+    Returns [n_total, ...] on every rank, in global view order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    n_max = (n_total + world - 1) // world
+    pad = n_max - local.shape[0]
+    if pad > 0:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    out = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    pieces = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        pieces.append(out[r * n_max:r * n_max + (hi - lo)])
+    return torch.cat(pieces, 0)
+
+
+def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None):
+    """render_view(i) -> dict of tensors for global view i (e.g. {'image': [H*W,3], 'depth': [H*W]}).
+    Each rank renders its contiguous block of views; one all_gather per key returns all views everywhere."""
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = shard_range(n_views, rank, world_size)
+    outs = [render_view(i) for i in range(lo, hi)]
+    keys = outs[0].keys() if outs else []
+    return {k: gather_views(torch.stack([o[k] for o in outs], 0), n_views, group) for k in keys}
