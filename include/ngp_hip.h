@@ -233,6 +233,11 @@ NGP_API int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const f
 NGP_API int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas,
                         float* rgbs, ngp_stream_t stream);
 
+/* Diagnostics: when a device buffer of >= 8 uint64 is set, k_render_iter adds per-phase wave-cycle sums
+ * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier).  NULL (default) = no
+ * stamp instruction executes. */
+NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
+
 /* ---------------- per-kernel device timing (bench.py roofline leg) ---------------- */
 /* When enabled, selected kernels are bracketed by hipEvents on their own stream.
  * ngp_prof_read synchronises the recorded events and returns accumulated milliseconds

@@ -124,8 +124,9 @@ struct Pcg32 {
 // Follows raymarching.cu:357-404 (identical text at :431-483 and :757-813).
 struct Dda {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, H3f, Cf, Hf, Hm1;
+    float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3f, Cf, Hf, Hm1, halfH;
     double Hd;
+    bool h_pow2;
     const uint8_t* grid;
 
     __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
@@ -135,11 +136,13 @@ struct Dda {
         rdx = 1 / dx; rdy = 1 / dy; rdz = 1 / dz;
         rH = 1 / (float)H;
         H3f = (float)(H * H * H);
-        bound = bound_; dt_gamma = dt_gamma_;
+        bound = bound_; rbound = 1 / bound_; dt_gamma = dt_gamma_;
         const float SQRT3 = 1.7320508075688772f;
         dt_min = 2 * SQRT3 / (float)max_steps;
         dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
         Cf = (float)C; Hf = (float)H; Hm1 = (float)(H - 1); Hd = (double)H;
+        h_pow2 = (H & (H - 1)) == 0;
+        halfH = 0.5f * Hf;
         grid = g;
     }
 
@@ -155,8 +158,12 @@ struct Dda {
         frexpf(mx, &e);
         return (int)fminf(Cf - 1, fmaxf(0.0f, (float)e));
     }
-    __device__ __forceinline__ int cell(float v, float mip_rbound) const {           // :378-380 (double product)
-        return (int)clampf((float)(0.5 * (double)fmaf(v, mip_rbound, 1.0f) * Hd), 0.0f, Hm1);
+    // :378-380.  The reference's `0.5 * (...) * H` is a double product; for a power-of-two H it only rescales the
+    // float value fmaf(v, rb, 1) by 2^k, which is exact in float as well, so the double detour is skipped.
+    __device__ __forceinline__ int cell(float v, float mip_rbound) const {
+        const float a = fmaf(v, mip_rbound, 1.0f);
+        const float s = h_pow2 ? a * halfH : (float)(0.5 * (double)a * Hd);
+        return (int)clampf(s, 0.0f, Hm1);
     }
 
     // Probe at t. Occupied: returns true with x,y,z,dt set (caller advances t += dt).
@@ -168,8 +175,12 @@ struct Dda {
         dt = clampf(t * dt_gamma, dt_min, dt_max);
         const int lp = mip_from_pos(x, y, z), ld = mip_from_dt(dt);
         const int level = lp > ld ? lp : ld;
-        const float mip_bound = fminf((float)(1 << level), bound);
-        const float mip_rbound = 1 / mip_bound;
+        // mip_bound = min(2^level, bound); 1 / mip_bound is exact for the power of two (built from its exponent)
+        // and the precomputed 1 / bound otherwise: same values as the reference's IEEE division (:373-374)
+        const float pw = (float)(1 << level);
+        const bool use_pw = pw <= bound;
+        const float mip_bound = use_pw ? pw : bound;
+        const float mip_rbound = use_pw ? __uint_as_float((uint32_t)(127 - level) << 23) : rbound;
         const int nx = cell(x, mip_rbound), ny = cell(y, mip_rbound), nz = cell(z, mip_rbound);
         const uint32_t index = (uint32_t)((float)level * H3f + (float)morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
         const bool occ = (grid[index >> 3] & (1u << (index & 7u))) != 0;

@@ -41,24 +41,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 8;                 // waves per workgroup
 constexpr int kThreads = kWaves * 64;     // 512
-constexpr int kGroup = kThreads;          // alive-list entries handled per workgroup pass
-constexpr int kMaxStep = 8;               // reference: n_step <= 8
-constexpr int kSlots = 64 * kMaxStep;     // sample slots per wave
+constexpr int kWavesPerSimd = 4;          // two 512-thread workgroups per CU (LDS: 2 x ~72 KB)
+constexpr int kCh = 2;                    // march steps handled per sub-pass (n_step <= 8 is processed in chunks of kCh)
+constexpr int kSlots = 64 * kCh;          // sample slots per wave and sub-pass
 constexpr int kLookahead = 4;             // iterations the host may enqueue beyond the last status it has seen
 constexpr int kRing = 8;
 
 // device-side loop state (ping-pong pair); also the pinned status record
 struct Ctl {
     uint32_t n_alive, n_step, step, done;
-    uint32_t iters, last_n_alive, last_n_step, pad;
+    uint32_t iters, last_n_alive, last_n_step, next_chunk;   // next_chunk: work-queue head of the iteration reading this record
     unsigned long long samples_marched, samples_slots;
 };
 
 // per-level table staged in LDS (16 levels)
 struct LevelTab {
     float scale[16];
-    uint32_t offset[16], size[16], mul1[16], mul2[16];
-    uint32_t flags[16];  // bit0 hashed, bits 1-2 mode
+    uint32_t offset[16], size[16];
+    uint32_t a1[16], a2[16];   // per-dimension multipliers: the hash primes for hashed levels, the dense strides otherwise
+    uint32_t mask[16];         // index reduction as an AND: size-1 (power-of-two size), ~0 (dense: already < size)
+    uint32_t flags[16];        // bit0 hashed, bit1 needs a generic modulo (only in the GENERIC kernel variants)
 };
 
 struct NetArgs {
@@ -176,43 +178,47 @@ __device__ __forceinline__ void sh4_quarter(uint32_t q, float x, float y, float 
     }
 }
 
-__device__ __forceinline__ uint32_t level_index(const LevelTab& lt, uint32_t level, uint32_t p0, uint32_t p1, uint32_t p2) {
-    const uint32_t fl = lt.flags[level];
-    uint32_t idx = (fl & 1u) ? (p0 ^ (p1 * 2654435761u) ^ (p2 * 805459861u)) : p0 + p1 * lt.mul1[level] + p2 * lt.mul2[level];
-    const uint32_t mode = fl >> 1;
-    if (mode == 1) idx &= lt.size[level] - 1;
-    else if (mode == 2) idx %= lt.size[level];
-    return idx;
-}
-
+template <bool GENERIC>
 __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
                                          float dx, float dy, float dz, float& sigma, float& cr, float& cg, float& cb) {
     const uint32_t q = lane >> 4;
     // encoder input: (x + bound) / (2 bound)  (gridencoder/grid.py:144)
-    const float u0 = (x + na.bound) / na.two_bound, u1 = (y + na.bound) / na.two_bound, u2 = (z + na.bound) / na.two_bound;
+    float u0 = (x + na.bound) / na.two_bound, u1 = (y + na.bound) / na.two_bound, u2 = (z + na.bound) / na.two_bound;
     const bool oob = (u0 < 0 || u0 > 1) || (u1 < 0 || u1 > 1) || (u2 < 0 || u2 > 1);
+    if (oob) { u0 = 0.5f; u1 = 0.5f; u2 = 0.5f; }  // keep the gathers in range; the features are zeroed below (gridencoder.cu:107-123)
     const float half_off = na.align_corners ? 0.0f : 0.5f;
 
-    // ---- 4 levels x 8 corners: issue all 32 gathers, then interpolate (gridencoder.cu:139-175)
+    // ---- 4 levels x 8 corners: issue all 32 gathers, then interpolate (gridencoder.cu:139-175).
+    // Index recipe of get_grid_index (:54-72), branch-free: hashed and dense candidates are both formed from the
+    // same two products and selected per level; the modulo is an AND (see LevelTab).
     uint32_t raw[4][8];
     float fr[4][3];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t level = q + 4 * i;
         const float scale = lt.scale[level];
+        const uint32_t a1 = lt.a1[level], a2 = lt.a2[level], mask = lt.mask[level], fl = lt.flags[level];
+        const bool hashed = (fl & 1u) != 0;
         float p[3] = {fmaf(u0, scale, half_off), fmaf(u1, scale, half_off), fmaf(u2, scale, half_off)};
         uint32_t g[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const float fl = floorf(p[d]);
-            g[d] = (uint32_t)fl;
+            const float fl_ = floorf(p[d]);
+            g[d] = (uint32_t)fl_;
             fr[i][d] = p[d] - (float)g[d];
         }
         const uint32_t* tab = na.table + lt.offset[level];
+        const uint32_t t1[2] = {g[1] * a1, g[1] * a1 + a1};
+        const uint32_t t2[2] = {g[2] * a2, g[2] * a2 + a2};
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
-            const uint32_t e = level_index(lt, level, g[0] + (idx & 1), g[1] + ((idx >> 1) & 1), g[2] + ((idx >> 2) & 1));
-            raw[i][idx] = oob ? 0u : tab[e];
+            const uint32_t px = g[0] + (idx & 1), ty = t1[(idx >> 1) & 1], tz = t2[(idx >> 2) & 1];
+            uint32_t e = hashed ? (px ^ ty ^ tz) : (px + ty + tz);
+            e &= mask;
+            if (GENERIC) {
+                if (fl & 2u) e %= lt.size[level];
+            }
+            raw[i][idx] = tab[e];
         }
     }
     half8 feat;
@@ -221,10 +227,11 @@ __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds
         _Float16 a0 = (_Float16)0, a1 = (_Float16)0;
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
-            float w = 1;
-            w *= (idx & 1) ? fr[i][0] : 1 - fr[i][0];
-            w *= (idx & 2) ? fr[i][1] : 1 - fr[i][1];
-            w *= (idx & 4) ? fr[i][2] : 1 - fr[i][2];
+            // w = ((1 * wx) * wy) * wz in the reference's order (:150-160); 1 * wx is exact
+            const float wx = (idx & 1) ? fr[i][0] : 1 - fr[i][0];
+            const float wy = (idx & 2) ? fr[i][1] : 1 - fr[i][1];
+            const float wz = (idx & 4) ? fr[i][2] : 1 - fr[i][2];
+            const float w = (wx * wy) * wz;
             const half2v g = __builtin_bit_cast(half2v, raw[i][idx]);
             a0 = a0 + mul_round_f16(w, g[0]);
             a1 = a1 + mul_round_f16(w, g[1]);
@@ -272,12 +279,14 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     if (threadIdx.x < 16) {
         const uint32_t l = threadIdx.x;
+        const uint32_t size = lv.offset[l + 1] - lv.offset[l];
         lt->scale[l] = lv.scale[l];
         lt->offset[l] = lv.offset[l];
-        lt->size[l] = lv.offset[l + 1] - lv.offset[l];
-        lt->mul1[l] = lv.mul1[l];
-        lt->mul2[l] = lv.mul2[l];
-        lt->flags[l] = (uint32_t)lv.hashed[l] | ((uint32_t)lv.mode[l] << 1);
+        lt->size[l] = size;
+        lt->a1[l] = lv.hashed[l] ? 2654435761u : lv.mul1[l];
+        lt->a2[l] = lv.hashed[l] ? 805459861u : lv.mul2[l];
+        lt->mask[l] = lv.mode[l] == 1 ? size - 1 : 0xFFFFFFFFu;
+        lt->flags[l] = (uint32_t)lv.hashed[l] | (lv.mode[l] == 2 ? 2u : 0u);
     }
     __syncthreads();
 }
@@ -285,6 +294,7 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
 // ------------------------------------------------------------------------------------------
 // NeRFNetwork.forward on an explicit point list (network_ff.py:51-75)
 // ------------------------------------------------------------------------------------------
+template <bool GENERIC>
 __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels lv, const float* __restrict__ xyzs,
                                                          const float* __restrict__ dirs, uint32_t M, float* __restrict__ sigmas,
                                                          float* __restrict__ rgbs) {
@@ -299,7 +309,7 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
         const uint32_t m = tile * 16 + c;
         const uint32_t mm = m < M ? m : M - 1;
         float sg, r, g, b;
-        net_tile(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], dirs[(size_t)mm * 3],
+        net_tile<GENERIC>(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], dirs[(size_t)mm * 3],
                  dirs[(size_t)mm * 3 + 1], dirs[(size_t)mm * 3 + 2], sg, r, g, b);
         if (lane < 16 && m < M) {
             sigmas[m] = sg;
@@ -320,140 +330,178 @@ struct RenderArgs {
     float *last_sigmas, *last_rgbs;   // optional dump of the iteration's slot-major outputs
     float pad_sigma, pad_r, pad_g, pad_b;
     const int32_t* alive_in;
-    int32_t* staging;                 // [groups*kGroup] block-local compacted survivors
-    uint32_t* group_count;            // [groups]
-    Ctl* ctl;                         // state read by this iteration
+    int32_t* staging;                 // [chunks*64] chunk-local compacted survivors
+    uint32_t* chunk_count;            // [chunks]
+    Ctl* ctl;                         // state read by this iteration (+ its work-queue head)
     const uint8_t* bitfield;
     uint32_t cascade, grid_size, max_steps, perturb;
     float dt_gamma;
     Pcg32 rng;
+    unsigned long long* stamps;       // diagnostics only (ngp_debug_set_stamps): per-phase cycle sums; NULL in normal runs
 };
 
-struct WaveSlab {  // per-wave LDS
+struct WaveSlab {  // per-wave LDS: kCh march steps of 64 rays
     float t[kSlots], dt[kSlots], sig[kSlots];
     uint32_t rg[kSlots], b[kSlots];
     uint16_t list[kSlots];
     float od[64][6];
 };
 
-__global__ void __launch_bounds__(kThreads) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
+template <bool GENERIC>
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
     const uint32_t n_alive = ctl.n_alive, n_step = ctl.n_step;
-    const uint32_t n_groups = (n_alive + kGroup - 1) / kGroup;
-    if (blockIdx.x >= n_groups) return;
+    const uint32_t n_chunks = (n_alive + 63) / 64;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
-    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(smem + w_bytes + sizeof(LevelTab));  // [kWaves]
-    WaveSlab* slabs = reinterpret_cast<WaveSlab*>(smem + w_bytes + sizeof(LevelTab) + 64);
-    stage_block(na, lv, Wlds, lt);
+    WaveSlab* slabs = reinterpret_cast<WaveSlab*>(smem + w_bytes + sizeof(LevelTab));
+    stage_block(na, lv, Wlds, lt);   // the only workgroup barrier: waves are independent from here on
 
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15;
     WaveSlab& S = slabs[wid];
+    unsigned long long ts0 = 0, ts1 = 0;
+#define NGP_STAMP(idx)                                                                  \
+    if (ra.stamps) {                                                                    \
+        ts1 = __builtin_amdgcn_s_memtime();                                             \
+        if (lane == 0) atomicAdd(ra.stamps + (idx), ts1 - ts0);                         \
+        ts0 = ts1;                                                                      \
+    }
 
-    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
-        const uint32_t entry = group * kGroup + wid * 64 + lane;
+    // every wave pulls 64-ray chunks from a device-side queue: no inter-wave coupling, no tail imbalance
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(&ra.ctl->next_chunk, 1u);
+        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        if (chunk >= n_chunks) break;
+        if (ra.stamps) ts0 = __builtin_amdgcn_s_memtime();
+
+        const uint32_t entry = chunk * 64 + lane;
         const bool active = entry < n_alive;
         const int32_t ray = active ? ra.alive_in[entry] : -1;
 
-        // ---- 1. march (raymarching.cu:706-814), lane = ray
-        uint32_t cnt = 0;
-        float t0 = 0, tp = 0;
+        Dda dda;
+        float t_march = 0, last_t = 0, t_c = 0, far = 0;
+        float ws = 0, dep = 0, cr = 0, cg = 0, cb = 0;
         if (active) {
-            Dda dda;
             dda.init(ra.rays_o + (size_t)ray * 3, ra.rays_d + (size_t)ray * 3, ra.bitfield, na.bound, ra.dt_gamma, ra.max_steps, ra.cascade,
                      ra.grid_size);
-            t0 = ra.rays_t[ray];
-            const float far = ra.fars[ray];
-            float t = t0;
+            t_c = ra.rays_t[ray];      // composite_rays' t (:848) accumulates from the unperturbed value
+            far = ra.fars[ray];
+            t_march = t_c;
             if (ra.perturb) {
                 Pcg32 rng = ra.rng;
                 rng.advance((int64_t)entry);
-                t += dda.dt_min * rng.next_float();
+                t_march += dda.dt_min * rng.next_float();
             }
-            tp = t;
-            float x, y, z, dt;
-            while (t < far && cnt < n_step) {
-                if (dda.probe(t, x, y, z, dt)) {
-                    S.t[lane * n_step + cnt] = t;
-                    S.dt[lane * n_step + cnt] = dt;
-                    t += dt;
-                    cnt++;
-                }
-            }
+            last_t = t_march;
+            ws = ra.weights_sum[ray]; dep = ra.depth[ray];
+            cr = ra.image[(size_t)ray * 3]; cg = ra.image[(size_t)ray * 3 + 1]; cb = ra.image[(size_t)ray * 3 + 2];
             S.od[lane][0] = dda.ox; S.od[lane][1] = dda.oy; S.od[lane][2] = dda.oz;
             S.od[lane][3] = dda.dx; S.od[lane][4] = dda.dy; S.od[lane][5] = dda.dz;
         }
-        // ---- 2. compact the wave's samples and run the network 16 at a time
-        uint32_t incl = cnt;
+        // ray states: running -> (terminated by T < 1e-4 | exhausted: the march ran out of samples) -> dead
+        bool running = active;
+        uint32_t steps_done = 0;      // samples composited so far (== n_step at the end <=> the ray survives)
+        uint32_t wave_samples = 0;
+
+        for (uint32_t s0 = 0; s0 < n_step; s0 += kCh) {
+            const uint32_t want = (n_step - s0) < (uint32_t)kCh ? (n_step - s0) : (uint32_t)kCh;
+            // ---- 1. march (raymarching.cu:757-813), lane = ray.  A ray whose compositing already stopped is not marched
+            //         further unless the caller asked for the reference's last-iteration tensors.
+            uint32_t cnt = 0;
+            const bool do_march = active && (running || ra.last_sigmas != nullptr);
+            if (do_march) {
+                float x, y, z, dt;
+                while (t_march < far && cnt < want) {
+                    if (dda.probe(t_march, x, y, z, dt)) {
+                        S.t[lane * kCh + cnt] = t_march;
+                        S.dt[lane * kCh + cnt] = dt;
+                        t_march += dt;
+                        cnt++;
+                    }
+                }
+            }
+            if (!__any(cnt != 0)) {
+                // nothing to evaluate in this sub-pass for the whole wave
+                if (running && cnt < want) running = false;
+                if (ra.last_sigmas && active)
+                    for (uint32_t k = 0; k < want; k++) {
+                        const size_t row = (size_t)entry * n_step + s0 + k;
+                        ra.last_sigmas[row] = ra.pad_sigma;
+                        ra.last_rgbs[row * 3] = ra.pad_r; ra.last_rgbs[row * 3 + 1] = ra.pad_g; ra.last_rgbs[row * 3 + 2] = ra.pad_b;
+                    }
+                if (!ra.last_sigmas && !__any(running)) break;
+                continue;
+            }
+            NGP_STAMP(0)
+            // ---- 2. compact the wave's samples and run the network 16 at a time
+            uint32_t incl = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, 64);
-            if (lane >= (uint32_t)off) incl += o;
-        }
-        const uint32_t total = __shfl(incl, 63, 64);
-        for (uint32_t k = 0; k < cnt; k++) S.list[incl - cnt + k] = (uint16_t)((lane << 3) | k);
-        // (single wave: LDS writes above are visible to the wave's later reads after the implicit waitcnt)
-        const uint32_t n_tiles = (total + 15) / 16;
-        for (uint32_t tile = 0; tile < n_tiles; tile++) {
-            const uint32_t j = tile * 16 + c;
-            const bool valid = j < total;
-            const uint32_t e = S.list[valid ? j : total - 1];
-            const uint32_t rl = e >> 3, slot = rl * n_step + (e & 7);
-            const float t = S.t[slot];
-            const float ox = S.od[rl][0], oy = S.od[rl][1], oz = S.od[rl][2];
-            const float dx = S.od[rl][3], dy = S.od[rl][4], dz = S.od[rl][5];
-            const float x = clampf(fmaf(t, dx, ox), -na.bound, na.bound);
-            const float y = clampf(fmaf(t, dy, oy), -na.bound, na.bound);
-            const float z = clampf(fmaf(t, dz, oz), -na.bound, na.bound);
-            float sg, r, g, b;
-            net_tile(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
-            if (lane < 16 && valid) {
-                S.sig[slot] = na.density_scale * sg;   // renderer.py:365
-                S.rg[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)r) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)g) << 16);
-                S.b[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b);
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= (uint32_t)off) incl += o;
             }
-        }
-        // ---- 3. composite (raymarching.cu:828-913), lane = ray
-        bool survive = false;
-        if (active) {
-            float t = t0, last_t = tp;
-            float ws = ra.weights_sum[ray], d = ra.depth[ray];
-            float r = ra.image[(size_t)ray * 3], g = ra.image[(size_t)ray * 3 + 1], b = ra.image[(size_t)ray * 3 + 2];
-            uint32_t step = 0;
-            while (step < n_step) {
-                if (step >= cnt) break;  // deltas[0] == 0: the march ran out of samples
-                const uint32_t slot = lane * n_step + step;
-                const float dt = S.dt[slot];
-                const float t_after = S.t[slot] + dt;
-                const float delta1 = t_after - last_t;
-                last_t = t_after;
-                const float sg = S.sig[slot];
-                const uint32_t rg = S.rg[slot];
-                const float cr = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg & 0xffffu));
-                const float cg = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg >> 16));
-                const float cb = (float)__builtin_bit_cast(_Float16, (uint16_t)(S.b[slot] & 0xffffu));
-                const float alpha = 1.0f - expf(-sg * dt);
-                const float T = 1 - ws;
-                const float w = alpha * T;
-                ws += w;
-                t += delta1;
-                d = fmaf(w, t, d);
-                r = fmaf(w, cr, r); g = fmaf(w, cg, g); b = fmaf(w, cb, b);
-                if ((double)T < 1e-4) break;
-                step++;
+            const uint32_t total = __shfl(incl, 63, 64);
+            for (uint32_t k = 0; k < cnt; k++) S.list[incl - cnt + k] = (uint16_t)((lane << 3) | k);
+            wave_samples += total;
+            const uint32_t n_tiles = (total + 15) / 16;
+            for (uint32_t tile = 0; tile < n_tiles; tile++) {
+                const uint32_t j = tile * 16 + c;
+                const bool valid = j < total;
+                const uint32_t e = S.list[valid ? j : total - 1];
+                const uint32_t rl = e >> 3, slot = rl * kCh + (e & 7);
+                const float t = S.t[slot];
+                const float ox = S.od[rl][0], oy = S.od[rl][1], oz = S.od[rl][2];
+                const float dx = S.od[rl][3], dy = S.od[rl][4], dz = S.od[rl][5];
+                const float x = clampf(fmaf(t, dx, ox), -na.bound, na.bound);
+                const float y = clampf(fmaf(t, dy, oy), -na.bound, na.bound);
+                const float z = clampf(fmaf(t, dz, oz), -na.bound, na.bound);
+                float sg, r, g, b;
+                net_tile<GENERIC>(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
+                if (lane < 16 && valid) {
+                    S.sig[slot] = na.density_scale * sg;   // renderer.py:365
+                    S.rg[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)r) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)g) << 16);
+                    S.b[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b);
+                }
             }
-            survive = step == n_step;
-            if (survive) ra.rays_t[ray] = t;
-            ra.weights_sum[ray] = ws; ra.depth[ray] = d;
-            ra.image[(size_t)ray * 3] = r; ra.image[(size_t)ray * 3 + 1] = g; ra.image[(size_t)ray * 3 + 2] = b;
-            if (ra.last_sigmas) {
-                for (uint32_t k = 0; k < n_step; k++) {
-                    const size_t row = (size_t)entry * n_step + k;
-                    const uint32_t slot = lane * n_step + k;
+            NGP_STAMP(1)
+            // ---- 3. composite (raymarching.cu:860-897), lane = ray
+            if (running) {
+                uint32_t k = 0;
+                for (; k < cnt; k++) {
+                    const uint32_t slot = lane * kCh + k;
+                    const float dt = S.dt[slot];
+                    const float t_after = S.t[slot] + dt;
+                    const float delta1 = t_after - last_t;   // deltas[1] as march_rays wrote it (:791-793)
+                    last_t = t_after;
+                    const float sg = S.sig[slot];
+                    const uint32_t rg = S.rg[slot];
+                    const float sr = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg & 0xffffu));
+                    const float sgc = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg >> 16));
+                    const float sb = (float)__builtin_bit_cast(_Float16, (uint16_t)(S.b[slot] & 0xffffu));
+                    const float alpha = 1.0f - expf(-sg * dt);
+                    const float T = 1 - ws;
+                    const float w = alpha * T;
+                    ws += w;
+                    t_c += delta1;
+                    dep = fmaf(w, t_c, dep);
+                    cr = fmaf(w, sr, cr); cg = fmaf(w, sgc, cg); cb = fmaf(w, sb, cb);
+                    if ((double)T < 1e-4) break;             // :890: this sample does not count as a completed step
+                }
+                steps_done += k;
+                if (k < want) running = false;               // early stop, or deltas[0] == 0 (march ran out of samples)
+            } else if (do_march && cnt) {
+                // keep the march's last_t chain consistent for a terminated ray that is still being dumped
+                last_t = S.t[lane * kCh + cnt - 1] + S.dt[lane * kCh + cnt - 1];
+            }
+            if (ra.last_sigmas && active) {
+                for (uint32_t k = 0; k < want; k++) {
+                    const size_t row = (size_t)entry * n_step + s0 + k;
+                    const uint32_t slot = lane * kCh + k;
                     const bool have = k < cnt;
                     ra.last_sigmas[row] = have ? S.sig[slot] : ra.pad_sigma;
                     ra.last_rgbs[row * 3] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.rg[slot] & 0xffffu)) : ra.pad_r;
@@ -461,67 +509,89 @@ __global__ void __launch_bounds__(kThreads) k_render_iter(NetArgs na, GridLevels
                     ra.last_rgbs[row * 3 + 2] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.b[slot] & 0xffffu)) : ra.pad_b;
                 }
             }
+            NGP_STAMP(2)
+            if (!ra.last_sigmas && !__any(running)) break;
         }
-        // ---- 4. stable block-local compaction of survivors
+        // rows of sub-passes skipped after the whole wave stopped (dump mode never skips, so nothing to fill here)
+
+        // ---- 4. write back state, chunk-local stable compaction of survivors
+        const bool survive = active && running && steps_done == n_step;
+        if (active) {
+            if (survive) ra.rays_t[ray] = t_c;
+            ra.weights_sum[ray] = ws; ra.depth[ray] = dep;
+            ra.image[(size_t)ray * 3] = cr; ra.image[(size_t)ray * 3 + 1] = cg; ra.image[(size_t)ray * 3 + 2] = cb;
+        }
         const unsigned long long ball = __ballot(survive);
-        const uint32_t wave_surv = (uint32_t)__popcll(ball);
         const uint32_t rank_in_wave = (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+        if (survive) ra.staging[(size_t)chunk * 64 + rank_in_wave] = ray;
         if (lane == 0) {
-            wave_cnt[wid] = wave_surv;
-            if (total) atomicAdd(&ra.ctl->samples_marched, (unsigned long long)total);
+            ra.chunk_count[chunk] = (uint32_t)__popcll(ball);
+            if (wave_samples) atomicAdd(&ra.ctl->samples_marched, (unsigned long long)wave_samples);
         }
-        __syncthreads();
-        uint32_t base = 0, block_total = 0;
-        for (uint32_t w = 0; w < (uint32_t)kWaves; w++) {
-            const uint32_t v = wave_cnt[w];
-            if (w < wid) base += v;
-            block_total += v;
+        // padding rows of the reference's [M_padded] tensors (M += 128 - M % 128), written by the last chunk's wave
+        if (ra.last_sigmas && chunk == n_chunks - 1) {
+            for (uint32_t i = lane; i < 128; i += 64) {
+                const size_t row = (size_t)n_alive * n_step + i;
+                ra.last_sigmas[row] = ra.pad_sigma;
+                ra.last_rgbs[row * 3] = ra.pad_r; ra.last_rgbs[row * 3 + 1] = ra.pad_g; ra.last_rgbs[row * 3 + 2] = ra.pad_b;
+            }
         }
-        if (survive) ra.staging[(size_t)group * kGroup + base + rank_in_wave] = ray;
-        if (threadIdx.x == 0) ra.group_count[group] = block_total;
-        __syncthreads();  // wave_cnt is reused by the next group
+        NGP_STAMP(3)
     }
-    // padding rows of the reference's [M_padded] tensors (M += 128 - M % 128), written by the last group's block
-    if (ra.last_sigmas && blockIdx.x == (n_groups - 1) % gridDim.x && threadIdx.x < 128) {
-        const size_t row = (size_t)n_alive * n_step + threadIdx.x;
-        ra.last_sigmas[row] = ra.pad_sigma;
-        ra.last_rgbs[row * 3] = ra.pad_r; ra.last_rgbs[row * 3 + 1] = ra.pad_g; ra.last_rgbs[row * 3 + 2] = ra.pad_b;
-    }
+#undef NGP_STAMP
 }
 
-// stitch group survivor lists -> next alive list; advance the reference's schedule (renderer.py:347-373)
+// stitch chunk survivor lists -> next alive list; advance the reference's schedule (renderer.py:347-373).
+// One 256-thread block per 8 chunks (512 alive entries): wave w copies chunks 2w, 2w+1 of its block.
 __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ cur, Ctl* __restrict__ nxt, const int32_t* __restrict__ staging,
-                                                         const uint32_t* __restrict__ group_count, int32_t* __restrict__ alive_out, uint32_t N,
+                                                         const uint32_t* __restrict__ chunk_count, int32_t* __restrict__ alive_out, uint32_t N,
                                                          uint32_t max_steps) {
     __shared__ uint32_t red[4];
+    __shared__ uint32_t local_off[9];
     const Ctl c = *cur;
     if (c.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = c;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { Ctl n = c; n.next_chunk = 0; *nxt = n; }
         return;
     }
-    const uint32_t n_groups = (c.n_alive + kGroup - 1) / kGroup;
+    const uint32_t n_chunks = (c.n_alive + 63) / 64;
+    const uint32_t n_blocks = (n_chunks + 7) / 8;
     const uint32_t g = blockIdx.x;
-    if (g >= n_groups) return;
+    if (g >= n_blocks) return;
+    const uint32_t first = g * 8;
     uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < g; j += 256) part += group_count[j];
+    for (uint32_t j = threadIdx.x; j < first; j += 256) part += chunk_count[j];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < 8; i++) {
+            local_off[i] = acc;
+            acc += (first + i < n_chunks) ? chunk_count[first + i] : 0;
+        }
+        local_off[8] = acc;
+    }
     __syncthreads();
     const uint32_t prefix = red[0] + red[1] + red[2] + red[3];
-    const uint32_t mine = group_count[g];
-    for (uint32_t i = threadIdx.x; i < mine; i += 256) alive_out[prefix + i] = staging[(size_t)g * kGroup + i];
-    if (g == n_groups - 1 && threadIdx.x == 0) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t ci = w * 2 + h;
+        const uint32_t cnt = local_off[ci + 1] - local_off[ci];
+        if (lane < cnt) alive_out[prefix + local_off[ci] + lane] = staging[(size_t)(first + ci) * 64 + lane];
+    }
+    if (g == n_blocks - 1 && threadIdx.x == 0) {
         Ctl n = c;
         n.last_n_alive = c.n_alive;
         n.last_n_step = c.n_step;
         n.iters = c.iters + 1;
         n.samples_slots = c.samples_slots + (unsigned long long)c.n_alive * c.n_step;
         n.step = c.step + c.n_step;
-        n.n_alive = prefix + mine;
+        n.n_alive = prefix + local_off[8];
         uint32_t ns = n.n_alive ? N / n.n_alive : 8;
         n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
         n.done = (n.n_alive == 0 || n.step >= max_steps) ? 1 : 0;
+        n.next_chunk = 0;
         *nxt = n;
     }
 }
@@ -554,7 +624,7 @@ struct ngp_render_ctx {
     uint32_t max_rays = 0;
     int32_t* alive[2] = {nullptr, nullptr};
     int32_t* staging = nullptr;
-    uint32_t* group_count = nullptr;
+    uint32_t* chunk_count = nullptr;
     float* rays_t = nullptr;
     Ctl* ctl = nullptr;          // device [2]
     _Float16* packed = nullptr;  // device
@@ -562,6 +632,8 @@ struct ngp_render_ctx {
     hipEvent_t ev[kRing];
     int num_cu = 256;
 };
+
+static unsigned long long* g_stamps = nullptr;
 
 static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
     NGP_REQUIRE(m && m->embeddings && m->offsets_host && m->sigma_weights && m->color_weights, "ngp_model: null pointer");
@@ -581,6 +653,12 @@ static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* pac
     return NGP_OK;
 }
 
+static bool needs_generic(const GridLevels& lv) {
+    for (int l = 0; l < 16; l++)
+        if (lv.mode[l] == 2) return true;
+    return false;
+}
+
 static size_t weights_bytes(const NetArgs& na) { return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2; }
 
 extern "C" {
@@ -590,12 +668,12 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     NGP_REQUIRE(max_rays > 0, "render_ctx_create: max_rays must be positive");
     ngp_render_ctx* c = new ngp_render_ctx();
     c->max_rays = max_rays;
-    const size_t groups = div_up(max_rays, kGroup);
+    const size_t chunks = div_up(max_rays, 64);
     bool ok = true;
     ok &= hipMalloc(&c->alive[0], (size_t)max_rays * 4) == hipSuccess;
     ok &= hipMalloc(&c->alive[1], (size_t)max_rays * 4) == hipSuccess;
-    ok &= hipMalloc(&c->staging, groups * kGroup * 4) == hipSuccess;
-    ok &= hipMalloc(&c->group_count, groups * 4) == hipSuccess;
+    ok &= hipMalloc(&c->staging, chunks * 64 * 4) == hipSuccess;
+    ok &= hipMalloc(&c->chunk_count, chunks * 4) == hipSuccess;
     ok &= hipMalloc(&c->rays_t, (size_t)max_rays * 4) == hipSuccess;
     ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
@@ -615,7 +693,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
 
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
-    (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->group_count);
+    (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
     (void)hipFree(c->rays_t); (void)hipFree(c->ctl); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
@@ -652,17 +730,21 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     ra.weights_sum = weights_sum; ra.depth = depth; ra.image = image;
     ra.last_sigmas = last_sigmas; ra.last_rgbs = last_rgbs;
     if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
-    ra.staging = ctx->staging; ra.group_count = ctx->group_count;
+    ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count;
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
+    ra.stamps = g_stamps;
 
-    const size_t lds = weights_bytes(na) + sizeof(LevelTab) + 64 + (size_t)kWaves * sizeof(WaveSlab);
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab);
+    const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    const bool generic = needs_generic(lv);
     NGP_REQUIRE(lds <= 160 * 1024, "render_rays: LDS budget exceeded (%zu bytes)", lds);
 
     uint32_t ub = N;          // host-side upper bound of n_alive
@@ -673,16 +755,19 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     Ctl last = {};
     while (!done) {
         const uint32_t cur = launched & 1;
-        const uint32_t groups = div_up(ub ? ub : 1, kGroup);
-        const uint32_t blocks = groups < (uint32_t)ctx->num_cu ? groups : (uint32_t)ctx->num_cu;  // one 512-thread workgroup per CU
+        const uint32_t chunks = div_up(ub ? ub : 1, 64);
+        const uint32_t max_blocks = (uint32_t)ctx->num_cu * blocks_per_cu;   // persistent: resident workgroups pull chunks from a queue
+        const uint32_t want_blocks = div_up(chunks, kWaves);
+        const uint32_t blocks = want_blocks < max_blocks ? want_blocks : max_blocks;
         ra.alive_in = ctx->alive[cur];
         ra.ctl = ctx->ctl + cur;
         {
             ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
-            k_render_iter<<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            if (generic) k_render_iter<true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else k_render_iter<false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
         }
-        k_render_compact<<<groups, 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->group_count, ctx->alive[cur ^ 1], N,
-                                                max_steps);
+        k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
+                                                           ctx->alive[cur ^ 1], N, max_steps);
         (void)hipMemcpyAsync(&ctx->status[launched % kRing], ctx->ctl + (cur ^ 1), sizeof(Ctl), hipMemcpyDeviceToHost, s);
         (void)hipEventRecord(ctx->ev[launched % kRing], s);
         launched++;
@@ -724,6 +809,11 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     return NGP_OK;
 }
 
+int ngp_debug_set_stamps(unsigned long long* device_buf) {
+    g_stamps = device_buf;
+    return NGP_OK;
+}
+
 int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, float* rgbs,
                         ngp_stream_t stream) {
     if (M == 0) return NGP_OK;
@@ -744,14 +834,16 @@ int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* 
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     const uint32_t n_tiles = div_up(M, 16);
     uint32_t blocks = div_up(n_tiles, 4);
     if (blocks > 1024) blocks = 1024;
     ProfScope prof("network_forward", s, M);
-    k_network_forward<<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    if (needs_generic(lv)) k_network_forward<true><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    else k_network_forward<false><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
     return check_launch("network_forward");
 }
 

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of k_render_iter (ngp_debug_set_stamps) on the bench workload."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nerfsafetyvalidation_amd import _lib
+from nerfsafetyvalidation_amd.nerf.utils import get_rays
+from nerfsafetyvalidation_amd.scene import StonehengeScene
+dev = torch.device('cuda:0'); lib = _lib.lib()
+sc = StonehengeScene(H=800, W=800, bound=2); model = sc.build_model(dev)
+poses = torch.from_numpy(sc.poses).to(dev)
+buf = torch.zeros(8, dtype=torch.int64, device=dev)
+with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+    for v in (0, 1):
+        r = get_rays(poses[v:v+1], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False)
+    lib.ngp_debug_set_stamps(buf.data_ptr())
+    for v in (2, 3, 4):
+        r = get_rays(poses[v:v+1], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False)
+    torch.cuda.synchronize(); lib.ngp_debug_set_stamps(None)
+b = buf.cpu().tolist(); tot = sum(b[:4])
+for n, v in zip(['march', 'encode+mlp tiles', 'composite', 'compaction+barrier'], b[:4]): print(f'{n:22s} {v:16d} {100*v/tot:6.2f} %')
