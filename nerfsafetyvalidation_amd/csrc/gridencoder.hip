@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t grid_entry(uint32_t gridtype, bool align_cor
     return index % hashmap_size;
 }
 
-// acc += w * g with the reference's scalar_t semantics (see oracle/ngp_oracle.c acc_mul):
+// acc += w * g with the reference's scalar_t semantics (c10::Half arithmetic, gridencoder.cu:169-172):
 // f32: one fma; f16: product rounded to half, then a half add.
 __device__ __forceinline__ void acc_mul(float& acc, float w, float g) { acc = fmaf(w, g, acc); }
 __device__ __forceinline__ void acc_mul(_Float16& acc, float w, _Float16 g) { acc = acc + mul_round_f16(w, g); }

@@ -67,7 +67,7 @@ struct NetArgs {
     const uint32_t* table;     // fp16 pairs viewed as u32
     const _Float16* packed;    // fragment-major weights (global)
     uint32_t sig_mm, col_mm;   // hidden->hidden matmuls
-    float bound, two_bound, density_scale;
+    float bound, inv_two_bound, density_scale;
     int align_corners;
 };
 
@@ -182,8 +182,9 @@ template <bool GENERIC>
 __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
                                          float dx, float dy, float dz, float& sigma, float& cr, float& cg, float& cb) {
     const uint32_t q = lane >> 4;
-    // encoder input: (x + bound) / (2 bound)  (gridencoder/grid.py:144)
-    float u0 = (x + na.bound) / na.two_bound, u1 = (y + na.bound) / na.two_bound, u2 = (z + na.bound) / na.two_bound;
+    // encoder input: (x + bound) / (2 bound)  (gridencoder/grid.py:144).  torch evaluates a division by a Python scalar on
+    // the GPU as a multiplication with the fp32 reciprocal; identical to the division whenever 2*bound is a power of two.
+    float u0 = (x + na.bound) * na.inv_two_bound, u1 = (y + na.bound) * na.inv_two_bound, u2 = (z + na.bound) * na.inv_two_bound;
     const bool oob = (u0 < 0 || u0 > 1) || (u1 < 0 || u1 > 1) || (u2 < 0 || u2 > 1);
     if (oob) { u0 = 0.5f; u1 = 0.5f; u2 = 0.5f; }  // keep the gathers in range; the features are zeroed below (gridencoder.cu:107-123)
     const float half_off = na.align_corners ? 0.0f : 0.5f;
@@ -647,7 +648,7 @@ static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* pac
     na.sig_mm = m->sigma_hidden_mm;
     na.col_mm = m->color_hidden_mm;
     na.bound = m->bound;
-    na.two_bound = 2 * m->bound;
+    na.inv_two_bound = 1.0f / (2 * m->bound);
     na.density_scale = m->density_scale;
     na.align_corners = m->align_corners;
     return NGP_OK;

@@ -30,6 +30,13 @@ def grid_offsets(input_dim=3, num_levels=16, base_resolution=16, log2_hashmap_si
     return np.array(offsets, dtype=np.int32), per_level_scale
 
 
+def encoder_input(xyzs, bound):
+    """(x + bound) / (2 bound) of gridencoder/grid.py:144 as torch evaluates it on a GPU: the division by a Python scalar is a
+    multiplication with the fp32 reciprocal (exactly the division whenever 2*bound is a power of two)."""
+    inv = np.float32(1.0) / np.float32(2 * bound)
+    return ((np.asarray(xyzs, np.float32) + np.float32(bound)) * inv).astype(np.float32)
+
+
 def oracle_grid_encode(inputs01, emb, offsets, per_level_scale, H=16, calc_grad=False, gridtype=0, align_corners=False):
     """inputs01 [B,D] f32 in [0,1]; emb [sO,C] f32/f16 -> outputs [B, L*C] (wrapper-level layout), dy_dx or None"""
     inputs01 = np.ascontiguousarray(inputs01, dtype=np.float32)
@@ -77,7 +84,7 @@ class OracleNetwork:
                    model.bound, model.num_layers, model.num_layers_color)
 
     def density(self, xyzs):
-        x01 = ((np.asarray(xyzs, np.float32) + np.float32(self.bound)) / np.float32(2 * self.bound)).astype(np.float32)
+        x01 = encoder_input(xyzs, self.bound)
         feat, _ = oracle_grid_encode(x01, self.emb16, self.offsets, self.pls)
         h = oracle_ffmlp(feat, self.sw, 32, 64, self.nl)
         sigma = np.exp(h[:, 0].astype(np.float32))
@@ -143,3 +150,57 @@ def pinhole_rays(pose, intr, H, W):
     rays_d = (d @ pose[:3, :3].T.astype(np.float32)).astype(np.float32)
     rays_o = np.broadcast_to(pose[:3, 3].astype(np.float32), rays_d.shape).copy()
     return rays_o, np.ascontiguousarray(rays_d)
+
+
+class OracleLinearNetwork:
+    """nerf/network.py (nn.Linear backbone, no bias, ReLU) in fp32 on oracle kernels; weights are nn.Linear.weight arrays."""
+
+    def __init__(self, emb32, offsets, per_level_scale, sigma_ws, color_ws, bound):
+        self.emb, self.offsets, self.pls, self.bound = np.ascontiguousarray(emb32, np.float32), offsets, per_level_scale, bound
+        self.sigma_ws = [np.ascontiguousarray(w, np.float32) for w in sigma_ws]
+        self.color_ws = [np.ascontiguousarray(w, np.float32) for w in color_ws]
+
+    @staticmethod
+    def _mlp(x, ws):
+        dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        blob = np.concatenate([w.reshape(-1) for w in ws]).astype(np.float32)
+        out = np.empty((x.shape[0], dims[-1]), np.float32)
+        O.mlp_f32(np.ascontiguousarray(x, np.float32), blob, x.shape[0], dims, out)
+        return out
+
+    def density(self, xyzs):
+        x01 = encoder_input(xyzs, self.bound)
+        feat, _ = oracle_grid_encode(x01, self.emb, self.offsets, self.pls)
+        h = self._mlp(feat, self.sigma_ws)
+        return np.exp(h[:, 0]), h[:, 1:]
+
+    def color(self, dirs, geo):
+        h = self._mlp(np.concatenate([oracle_sh(dirs), geo], 1), self.color_ws)
+        return (1.0 / (1.0 + np.exp(-h))).astype(np.float32)
+
+    def forward(self, xyzs, dirs):
+        sigma, geo = self.density(xyzs)
+        return sigma, self.color(dirs, geo)
+
+
+def oracle_run(net, rays_o, rays_d, bound, density_scale, num_steps, min_near=0.2, bg=1.0):
+    """NeRFRenderer.run without upsampling (nerf/renderer.py:125-258) on oracle kernels; fp32."""
+    rays_o = np.ascontiguousarray(rays_o, np.float32).reshape(-1, 3)
+    rays_d = np.ascontiguousarray(rays_d, np.float32).reshape(-1, 3)
+    N, T = rays_o.shape[0], num_steps
+    aabb = np.array([-bound, -bound, -bound, bound, bound, bound], np.float32)
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    O.near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars)
+    z = (nears[:, None] + (fars - nears)[:, None] * np.linspace(0, 1, T, dtype=np.float32)[None]).astype(np.float32)
+    xyz = np.clip(rays_o[:, None] + rays_d[:, None] * z[..., None], -bound, bound).astype(np.float32)
+    sigma, geo = net.density(xyz.reshape(-1, 3))
+    sigma = sigma.reshape(N, T)
+    deltas = np.concatenate([z[:, 1:] - z[:, :-1], ((fars - nears) / T)[:, None]], 1).astype(np.float32)
+    alphas = 1 - np.exp(-deltas * np.float32(density_scale) * sigma)
+    trans = np.cumprod(np.concatenate([np.ones((N, 1), np.float32), 1 - alphas + np.float32(1e-15)], 1), 1)[:, :-1]
+    w = (alphas * trans).astype(np.float32)
+    rgb = net.color(np.repeat(rays_d, T, 0), geo).reshape(N, T, 3) * (w > 1e-4)[..., None]
+    ws = w.sum(1)
+    image = (w[..., None] * rgb).sum(1) + (1 - ws)[:, None] * bg
+    depth = (w * np.clip((z - nears[:, None]) / (fars - nears)[:, None], 0, 1)).sum(1)
+    return dict(image=image, depth=depth, weights_sum=ws, aggregated_density=(w * sigma).sum(1), sigmas=sigma, rgbs=rgb)

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the REFERENCE's own host Python in the dev container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is pinned: the reference modules nerf/utils.py::get_rays, gridencoder/grid.py (wrapper layout, autograd
+plumbing), shencoder/sphere_harmonics.py, nerf/network.py::NeRFNetwork and nerf/renderer.py::NeRFRenderer
+({render, run, run_cuda}) are imported from /root/reference unmodified and executed on CPU.  Their CUDA
+extension modules (`_gridencoder`, `_shencoder`) and the `raymarching` package (whose wrappers force
+`.cuda()`, raymarching/raymarching.py:34-35) are replaced IN MEMORY by thin shims over the CPU oracle
+(oracle/ngp_oracle.c), and absent third-party imports (cv2, trimesh, ...) by MagicMock.  Nothing of the
+reference is copied: the fixtures hold inputs, seeds and output arrays only.
+
+The GPU tests (tests/test_golden_gpu.py) rebuild the same inputs from the stored seeds/arrays, run this
+repo's modules on the MI355X and compare with the stored outputs; tests/test_golden_cpu.py re-checks the
+oracle against the same files without a GPU.  /root/reference is NOT needed at test time.
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402
+from nerfsafetyvalidation_amd import scene as SC  # noqa: E402  (pure numpy scene generator: poses, occupancy)
+
+# ---- 1. stand-ins for absent third-party modules (never executed on this path) ------------------------------
+for name in ["cv2", "trimesh", "mcubes", "tensorboardX", "torch_ema", "lpips", "imageio"]:
+    if name not in sys.modules:
+        sys.modules[name] = MagicMock()
+
+# ---- 2. native-module shims over the oracle -----------------------------------------------------------------
+_ge = types.ModuleType("_gridencoder")
+_ge.grid_encode_forward = lambda inputs, emb, offsets, out, B, D, C, L, S, H, cg, dy_dx, gt, ac: O.grid_encode_forward(
+    inputs, emb, offsets, out, B, D, C, L, float(S), H, cg, dy_dx if cg else None, gt, ac)
+_ge.grid_encode_backward = lambda grad, inputs, emb, offsets, ge, B, D, C, L, S, H, cg, dy_dx, gi, gt, ac: O.grid_encode_backward(
+    grad, inputs, emb, offsets, ge, B, D, C, L, float(S), H, cg, dy_dx if cg else None, gi if cg else None, gt, ac)
+sys.modules["_gridencoder"] = _ge
+
+_sh = types.ModuleType("_shencoder")
+_sh.sh_encode_forward = lambda inputs, out, B, D, C, cg, dy_dx: O.sh_encode_forward(inputs, out, B, D, C, cg, dy_dx if cg else None)
+_sh.sh_encode_backward = lambda grad, inputs, B, D, C, dy_dx, gi: O.sh_encode_backward(grad, inputs, B, D, C, dy_dx, gi)
+sys.modules["_shencoder"] = _sh
+
+
+def _make_raymarching_shim():
+    """CPU `raymarching` package with the reference wrappers' semantics (shapes, padding, in-place updates)."""
+    m = types.ModuleType("raymarching")
+
+    def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3).float(), rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        nears, fars = torch.empty(N), torch.empty(N)
+        O.near_far_from_aabb(rays_o, rays_d, aabb.contiguous().float(), N, min_near, nears, fars)
+        return nears, fars
+
+    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1, perturb=False,
+                   dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3).float(), rays_d.contiguous().view(-1, 3).float()
+        M = n_alive * n_step
+        if align > 0:
+            M += align - (M % align)
+        xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        O.march_rays(n_alive, n_step, rays_alive.contiguous(), rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, density_bitfield, near,
+                     far, xyzs, dirs, deltas, int(perturb))
+        return xyzs, dirs, deltas
+
+    def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+        O.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas.float().contiguous(), rgbs.float().contiguous(), deltas, weights_sum,
+                         depth, image)
+        return tuple()
+
+    def sph_from_ray(rays_o, rays_d, radius):
+        raise NotImplementedError
+
+    m.near_far_from_aabb, m.march_rays, m.composite_rays, m.sph_from_ray = near_far_from_aabb, march_rays, composite_rays, sph_from_ray
+    return m
+
+
+sys.modules["raymarching"] = _make_raymarching_shim()
+
+# ---- 3. the reference's host code ---------------------------------------------------------------------------
+sys.path.insert(0, REF)
+from nerf.utils import get_rays as ref_get_rays  # noqa: E402
+from gridencoder.grid import GridEncoder as RefGridEncoder  # noqa: E402
+from shencoder.sphere_harmonics import SHEncoder as RefSHEncoder  # noqa: E402
+from nerf.network import NeRFNetwork as RefNetwork  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path)} bytes)")
+
+
+def gen_get_rays():
+    H, W = 12, 20
+    intr = SC.intrinsics(H, W)
+    poses = SC.orbit_poses()[[0, 57, 123]]
+    out = ref_get_rays(torch.from_numpy(poses), intr, H, W)
+    save("get_rays.npz", poses=poses, intrinsics=intr, H=H, W=W, rays_o=out["rays_o"].numpy(), rays_d=out["rays_d"].numpy())
+
+
+def gen_grid_wrapper():
+    torch.manual_seed(11)
+    enc = RefGridEncoder(input_dim=3, num_levels=6, level_dim=2, base_resolution=4, log2_hashmap_size=9, desired_resolution=96)
+    enc.embeddings.data.uniform_(-0.5, 0.5)
+    # bound is a power of two: torch divides by the scalar 2*bound as a multiplication with its reciprocal on the GPU
+    # but as a true division on the CPU; for 2^k both are exact and the fixture is device independent
+    x = (torch.rand(257, 3) * 2 - 1) * 2.0
+    x[0] = 2.0
+    x[1] = -2.0
+    x.requires_grad_(True)
+    y = enc(x, bound=2.0)
+    g = torch.randn_like(y)
+    y.backward(g)
+    save("grid_wrapper.npz", embeddings=enc.embeddings.detach().numpy(), offsets=enc.offsets.numpy(), per_level_scale=enc.per_level_scale,
+         x=x.detach().numpy(), bound=2.0, y=y.detach().numpy(), g=g.numpy(), grad_x=x.grad.numpy(), grad_emb=enc.embeddings.grad.numpy())
+
+
+def gen_sh_wrapper():
+    torch.manual_seed(12)
+    d = torch.randn(130, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    outs = {}
+    for deg in (1, 4, 8):
+        dd = d.clone().requires_grad_(True)
+        y = RefSHEncoder(degree=deg)(dd)
+        g = torch.randn_like(y)
+        y.backward(g)
+        outs[f"y{deg}"], outs[f"g{deg}"], outs[f"gx{deg}"] = y.detach().numpy(), g.numpy(), dd.grad.numpy()
+    save("sh_wrapper.npz", d=d.numpy(), **outs)
+
+
+def _ref_network(bound, cuda_ray, density_scale):
+    torch.manual_seed(5)
+    net = RefNetwork(encoding="hashgrid", bound=bound, cuda_ray=cuda_ray, density_scale=density_scale, min_near=0.2, density_thresh=0.01,
+                     bg_radius=-1)
+    g = torch.Generator().manual_seed(0)
+    net.encoder.embeddings.data.copy_((torch.rand(net.encoder.embeddings.shape, generator=g) - 0.5).half().float())
+    return net.eval()
+
+
+def _weights(net):
+    return {f"sigma{i}": l.weight.detach().numpy() for i, l in enumerate(net.sigma_net)} | {
+        f"color{i}": l.weight.detach().numpy() for i, l in enumerate(net.color_net)}
+
+
+def gen_run():
+    """NeRFRenderer.render(staged=True) -> run : the path validate.py -O executes (fp32 here; no autocast on CPU)."""
+    bound, H, W = 2, 10, 14
+    net = _ref_network(bound, False, 48.0)
+    intr = SC.intrinsics(H, W)
+    pose = SC.orbit_poses()[160:161]
+    rays = ref_get_rays(torch.from_numpy(pose), intr, H, W)
+    res = {}
+    with torch.no_grad():
+        for tag, kw in {"u0": dict(num_steps=48, upsample_steps=0), "u16": dict(num_steps=32, upsample_steps=16)}.items():
+            out = net.render(rays["rays_o"], rays["rays_d"], staged=True, max_ray_batch=64, bg_color=1, perturb=False, **kw)
+            for k in ("image", "depth", "aggregated_density", "rgbs", "sigmas"):
+                res[f"{tag}_{k}"] = out[k].numpy()
+    save("render_run.npz", bound=bound, H=H, W=W, view=160, density_scale=48.0, table_seed=0, max_ray_batch=64, **_weights(net), **res)
+
+
+def gen_run_cuda():
+    """NeRFRenderer.run_cuda, eval branch, driven by the reference's own Python loop (renderer.py:329-378)."""
+    bound, H, W = 2, 12, 12
+    sc = SC.StonehengeScene(H=H, W=W, bound=bound)
+    net = _ref_network(bound, True, 48.0)
+    net.density_bitfield = torch.from_numpy(sc.bitfield())
+    intr = SC.intrinsics(H, W)
+    pose = SC.orbit_poses()[7:8]
+    rays = ref_get_rays(torch.from_numpy(pose), intr, H, W)
+    with torch.no_grad():
+        out = net.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)
+    save("render_run_cuda.npz", bound=bound, H=H, W=W, view=7, density_scale=48.0, table_seed=0, bitfield_sha256=SC.bitfield_sha256(sc.bitfield()),
+         image=out["image"].numpy(), depth=out["depth"].numpy(), last_sigmas=out["sigmas"].numpy(), last_rgbs=out["rgbs"].numpy(),
+         **_weights(net))
+
+
+if __name__ == "__main__":
+    gen_get_rays()
+    gen_grid_wrapper()
+    gen_sh_wrapper()
+    gen_run()
+    gen_run_cuda()
+    # keep the reference tree pristine
+    import shutil
+    for dirpath, dirnames, _ in os.walk(REF):
+        for d in list(dirnames):
+            if d == "__pycache__":
+                shutil.rmtree(os.path.join(dirpath, d), ignore_errors=True)

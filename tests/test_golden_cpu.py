@@ -1,0 +1,90 @@
+"""The oracle (and its numpy drivers) against the committed fixtures produced by the reference's own host Python
+(tests/golden/make_golden.py).  No GPU, no /root/reference needed."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as Hh
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def seeded_table(n_rows, seed=0):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(n_rows, 2, generator=g) - 0.5).half().float().numpy()
+
+
+def test_get_rays_restatement_matches_reference():
+    f = load("get_rays.npz")
+    for b in range(f["poses"].shape[0]):
+        ro, rd = Hh.pinhole_rays(f["poses"][b], f["intrinsics"], int(f["H"]), int(f["W"]))
+        np.testing.assert_allclose(rd, f["rays_d"][b], rtol=0, atol=3e-7)
+        assert np.array_equal(ro, f["rays_o"][b])
+
+
+def test_grid_wrapper_forward_backward():
+    f = load("grid_wrapper.npz")
+    bound = float(f["bound"])
+    x01 = ((f["x"] + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)
+    y, dydx = Hh.oracle_grid_encode(x01, f["embeddings"], f["offsets"], float(f["per_level_scale"]), H=4, calc_grad=True)
+    assert np.array_equal(y, f["y"])          # same oracle underneath: the reference WRAPPER's [L,B,C]->[B,LC] layout is what is pinned
+    B, D = x01.shape
+    L, C = len(f["offsets"]) - 1, f["embeddings"].shape[1]
+    gl = np.ascontiguousarray(f["g"].reshape(B, L, C).transpose(1, 0, 2))
+    ge, gi = np.zeros_like(f["embeddings"]), np.zeros((B, D), np.float32)
+    O.grid_encode_backward(gl, x01, f["embeddings"], f["offsets"], ge, B, D, C, L, float(np.log2(float(f["per_level_scale"]))), 4, True, dydx, gi, 0,
+                           False)
+    np.testing.assert_allclose(gi / (2 * bound), f["grad_x"], rtol=1e-5, atol=1e-6)   # chain rule of (x + bound) / (2 bound)
+    np.testing.assert_allclose(ge, f["grad_emb"], rtol=1e-5, atol=1e-6)
+
+
+def test_sh_wrapper():
+    f = load("sh_wrapper.npz")
+    for deg in (1, 4, 8):
+        assert np.array_equal(Hh.oracle_sh(f["d"], deg), f[f"y{deg}"])
+
+
+def _linear_net(f, bound):
+    offsets, pls = Hh.grid_offsets(desired_resolution=2048 * bound)
+    emb = seeded_table(int(offsets[-1]), int(f["table_seed"]))
+    return Hh.OracleLinearNetwork(emb, offsets, pls, [f["sigma0"], f["sigma1"]], [f["color0"], f["color1"], f["color2"]], bound)
+
+
+def test_run_restatement_matches_reference_renderer():
+    """oracle_run (numpy restatement of NeRFRenderer.run) == the reference's nerf/renderer.py driven on CPU"""
+    from nerfsafetyvalidation_amd import scene as SC
+    f = load("render_run.npz")
+    bound, H, W = int(f["bound"]), int(f["H"]), int(f["W"])
+    net = _linear_net(f, bound)
+    ro, rd = Hh.pinhole_rays(SC.orbit_poses()[int(f["view"])], SC.intrinsics(H, W), H, W)
+    out = Hh.oracle_run(net, ro, rd, bound, float(f["density_scale"]), 48)
+    np.testing.assert_allclose(out["image"], f["u0_image"][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["depth"], f["u0_depth"][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["aggregated_density"], f["u0_aggregated_density"][0], rtol=1e-4, atol=1e-4)
+
+
+def test_run_cuda_restatement_matches_reference_renderer():
+    """oracle_run_cuda (numpy restatement of the eval loop) == the reference's own Python loop, same oracle kernels"""
+    from nerfsafetyvalidation_amd import scene as SC
+    f = load("render_run_cuda.npz")
+    bound, H, W = int(f["bound"]), int(f["H"]), int(f["W"])
+    sc = SC.StonehengeScene(H=H, W=W, bound=bound)
+    bitfield = sc.bitfield()
+    assert SC.bitfield_sha256(bitfield) == str(f["bitfield_sha256"])
+    net = _linear_net(f, bound)
+    ro, rd = Hh.pinhole_rays(sc.poses[int(f["view"])], sc.intrinsics, H, W)
+    out = Hh.oracle_run_cuda(net, ro, rd, bitfield, bound, sc.cascade, float(f["density_scale"]))
+    img = out["image"] + (1 - out["weights_sum"])[:, None]
+    dep = np.clip(out["depth"] - out["nears"], 0, None) / (out["fars"] - out["nears"])
+    np.testing.assert_allclose(img, f["image"][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dep, f["depth"][0], rtol=0, atol=2e-5)
+    n_alive, n_step = out["schedule"][-1]
+    M = n_alive * n_step
+    assert f["last_sigmas"].shape[0] == M + 128 - M % 128      # F11 padding of the last iteration's tensors
