@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-stride", type=int, default=16, help="cpu_baseline renders rays[::stride] of view 0")
     p.add_argument("--profile-steps", type=int, default=3)
+    p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
     return p.parse_args()
 
 
@@ -60,6 +61,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     lib = _lib.lib()
+    if args.debug_flags:
+        lib.ngp_debug_disable_march_queue(args.debug_flags)
 
     H = W = args.size
     sc = StonehengeScene(H=H, W=W, bound=2)

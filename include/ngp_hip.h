@@ -237,6 +237,12 @@ NGP_API int ngp_network_forward(const ngp_model* model, const float* xyzs, const
  * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier).  NULL (default) = no
  * stamp instruction executes. */
 NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
+/* Diagnostics: uint32[N] device buffer receiving, per ray, an FNV-1a hash over the bit patterns of (dt, deltas[1]) of every
+ * sample the fused renderer marched, in order (NULL = off).  Lets a test prove the fused path's sample sequence equal to
+ * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 1 disables the coarse occupancy filter (A/B
+ * experiments; bit 0 is reserved -- a march-ahead sample queue was measured slower and removed). */
+NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
+NGP_API int ngp_debug_disable_march_queue(int off);
 
 /* ---------------- per-kernel device timing (bench.py roofline leg) ---------------- */
 /* When enabled, selected kernels are bracketed by hipEvents on their own stream.

@@ -72,6 +72,8 @@ SIGNATURES = {
                         C.POINTER(C.c_float), C.POINTER(RenderStats), _int, _vp],
     "ngp_network_forward": [C.POINTER(ModelStruct), _vp, _vp, _u32, _vp, _vp, _vp],
     "ngp_debug_set_stamps": [_vp],
+    "ngp_debug_set_sample_hash": [_vp],
+    "ngp_debug_disable_march_queue": [_int],
     "ngp_prof_enable": [_int],
     "ngp_prof_reset": [],
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],

@@ -76,6 +76,18 @@ __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
 __device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
     return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
 }
+// Same function for v < 1024 (grid cell coordinates: H <= 1024): the products above only ever add disjoint bit fields,
+// so they are ORs of shifts -- full-rate instructions instead of quarter-rate v_mul_lo_u32.
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+    v = (v | (v << 16)) & 0xFF0000FFu;
+    v = (v | (v << 8)) & 0x0F00F00Fu;
+    v = (v | (v << 4)) & 0xC30C30C3u;
+    v = (v | (v << 2)) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3D_cell(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits10(x) | (expand_bits10(y) << 1) | (expand_bits10(z) << 2);
+}
 __device__ __forceinline__ uint32_t morton3D_invert(uint32_t x) {
     x = x & 0x49249249u;
     x = (x | (x >> 2)) & 0xc30c30c3u;
@@ -126,7 +138,8 @@ struct Dda {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
     float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3f, Cf, Hf, Hm1, halfH;
     double Hd;
-    bool h_pow2;
+    bool h_pow2, const_dt;
+    int level_dt0;
     const uint8_t* grid;
 
     __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
@@ -144,6 +157,9 @@ struct Dda {
         h_pow2 = (H & (H - 1)) == 0;
         halfH = 0.5f * Hf;
         grid = g;
+        // dt_gamma == 0 (the default): clamp(t * 0, dt_min, dt_max) == dt_min for every t, so the step and its mip level are constants
+        const_dt = dt_gamma_ == 0.0f;
+        level_dt0 = mip_from_dt(dt_min);
     }
 
     __device__ __forceinline__ int mip_from_pos(float x, float y, float z) const {   // :44-49
@@ -168,12 +184,14 @@ struct Dda {
 
     // Probe at t. Occupied: returns true with x,y,z,dt set (caller advances t += dt).
     // Empty: t is advanced past the next voxel boundary (:386-403) and false is returned.
-    __device__ __forceinline__ bool probe(float& t, float& x, float& y, float& z, float& dt) const {
+    // `coarse` (optional, LDS): one bit per 64 consecutive cells of the Morton-ordered bitfield (= a 4x4x4 block); a clear
+    // bit proves the probed cell empty without touching global memory.
+    __device__ __forceinline__ bool probe(float& t, float& x, float& y, float& z, float& dt, const uint32_t* coarse = nullptr) const {
         x = clampf(fmaf(t, dx, ox), -bound, bound);
         y = clampf(fmaf(t, dy, oy), -bound, bound);
         z = clampf(fmaf(t, dz, oz), -bound, bound);
-        dt = clampf(t * dt_gamma, dt_min, dt_max);
-        const int lp = mip_from_pos(x, y, z), ld = mip_from_dt(dt);
+        dt = const_dt ? dt_min : clampf(t * dt_gamma, dt_min, dt_max);
+        const int lp = mip_from_pos(x, y, z), ld = const_dt ? level_dt0 : mip_from_dt(dt);
         const int level = lp > ld ? lp : ld;
         // mip_bound = min(2^level, bound); 1 / mip_bound is exact for the power of two (built from its exponent)
         // and the precomputed 1 / bound otherwise: same values as the reference's IEEE division (:373-374)
@@ -182,14 +200,20 @@ struct Dda {
         const float mip_bound = use_pw ? pw : bound;
         const float mip_rbound = use_pw ? __uint_as_float((uint32_t)(127 - level) << 23) : rbound;
         const int nx = cell(x, mip_rbound), ny = cell(y, mip_rbound), nz = cell(z, mip_rbound);
-        const uint32_t index = (uint32_t)((float)level * H3f + (float)morton3D((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-        const bool occ = (grid[index >> 3] & (1u << (index & 7u))) != 0;
+        const uint32_t index = (uint32_t)((float)level * H3f + (float)morton3D_cell((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        bool occ;
+        if (coarse != nullptr && ((coarse[index >> 11] >> ((index >> 6) & 31u)) & 1u) == 0) occ = false;
+        else occ = (grid[index >> 3] & (1u << (index & 7u))) != 0;
         if (!occ) {
             const float tx = fmaf(fmaf(0.5f, signf(dx), (float)nx + 0.5f) * rH * 2 - 1, mip_bound, -x) * rdx;
             const float ty = fmaf(fmaf(0.5f, signf(dy), (float)ny + 0.5f) * rH * 2 - 1, mip_bound, -y) * rdy;
             const float tz = fmaf(fmaf(0.5f, signf(dz), (float)nz + 0.5f) * rH * 2 - 1, mip_bound, -z) * rdz;
             const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-            do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+            if (const_dt) {
+                do { t += dt_min; } while (t < tt);
+            } else {
+                do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+            }
         }
         return occ;
     }

@@ -44,6 +44,7 @@ constexpr int kThreads = kWaves * 64;     // 512
 constexpr int kWavesPerSimd = 4;          // two 512-thread workgroups per CU (LDS: 2 x ~72 KB)
 constexpr int kCh = 2;                    // march steps handled per sub-pass (n_step <= 8 is processed in chunks of kCh)
 constexpr int kSlots = 64 * kCh;          // sample slots per wave and sub-pass
+constexpr size_t kCoarseMaxBytes = 8192;  // LDS budget for the coarse occupancy filter (C * H^3 / 64 bits)
 constexpr int kLookahead = 4;             // iterations the host may enqueue beyond the last status it has seen
 constexpr int kRing = 8;
 
@@ -321,6 +322,15 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
     }
 }
 
+// one bit per aligned 8-byte word (= 64 Morton-consecutive cells = one 4x4x4 block) of the occupancy bitfield
+__global__ void __launch_bounds__(256) k_build_coarse(const unsigned long long* __restrict__ bitfield64, uint32_t n_words,
+                                                       unsigned long long* __restrict__ coarse) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool any = i < n_words && bitfield64[i] != 0ull;
+    const unsigned long long m = __ballot(any);
+    if ((threadIdx.x & 63) == 0 && i < n_words) coarse[i >> 6] = m;
+}
+
 // ------------------------------------------------------------------------------------------
 // render iteration
 // ------------------------------------------------------------------------------------------
@@ -338,6 +348,9 @@ struct RenderArgs {
     uint32_t cascade, grid_size, max_steps, perturb;
     float dt_gamma;
     Pcg32 rng;
+    const uint32_t* coarse;           // coarse occupancy (k_build_coarse), staged into LDS; NULL = unfiltered probes
+    uint32_t coarse_words;            // its size in 32-bit words
+    uint32_t* sample_hash;            // diagnostics (ngp_debug_set_sample_hash): per-ray FNV hash of the marched (dt, delta1) bit patterns
     unsigned long long* stamps;       // diagnostics only (ngp_debug_set_stamps): per-phase cycle sums; NULL in normal runs
 };
 
@@ -360,6 +373,9 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
     WaveSlab* slabs = reinterpret_cast<WaveSlab*>(smem + w_bytes + sizeof(LevelTab));
+    uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(smem + w_bytes + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab));
+    for (uint32_t i = threadIdx.x; i < ra.coarse_words; i += blockDim.x) coarse_lds[i] = ra.coarse[i];
+    const uint32_t* coarse = ra.coarse_words ? coarse_lds : nullptr;
     stage_block(na, lv, Wlds, lt);   // the only workgroup barrier: waves are independent from here on
 
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15;
@@ -404,6 +420,9 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             S.od[lane][0] = dda.ox; S.od[lane][1] = dda.oy; S.od[lane][2] = dda.oz;
             S.od[lane][3] = dda.dx; S.od[lane][4] = dda.dy; S.od[lane][5] = dda.dz;
         }
+        float last_m = last_t;               // march-side copy of last_t (sample-hash diagnostics)
+        uint32_t hsh = 0;
+        if (active && ra.sample_hash) hsh = ra.sample_hash[ray];
         // ray states: running -> (terminated by T < 1e-4 | exhausted: the march ran out of samples) -> dead
         bool running = active;
         uint32_t steps_done = 0;      // samples composited so far (== n_step at the end <=> the ray survives)
@@ -418,10 +437,16 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             if (do_march) {
                 float x, y, z, dt;
                 while (t_march < far && cnt < want) {
-                    if (dda.probe(t_march, x, y, z, dt)) {
+                    if (dda.probe(t_march, x, y, z, dt, coarse)) {
                         S.t[lane * kCh + cnt] = t_march;
                         S.dt[lane * kCh + cnt] = dt;
                         t_march += dt;
+                        if (ra.sample_hash) {
+                            const float d1 = t_march - last_m;
+                            last_m = t_march;
+                            hsh = (hsh ^ __float_as_uint(dt)) * 16777619u;
+                            hsh = (hsh ^ __float_as_uint(d1)) * 16777619u;
+                        }
                         cnt++;
                     }
                 }
@@ -519,6 +544,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         const bool survive = active && running && steps_done == n_step;
         if (active) {
             if (survive) ra.rays_t[ray] = t_c;
+            if (ra.sample_hash) ra.sample_hash[ray] = hsh;
             ra.weights_sum[ray] = ws; ra.depth[ray] = dep;
             ra.image[(size_t)ray * 3] = cr; ra.image[(size_t)ray * 3 + 1] = cg; ra.image[(size_t)ray * 3 + 2] = cb;
         }
@@ -599,9 +625,11 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __restrict__ nears, float* __restrict__ rays_t,
                                                       int32_t* __restrict__ alive, float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                      float* __restrict__ image, Ctl* __restrict__ ctl, uint32_t max_steps) {
+                                                      float* __restrict__ image, Ctl* __restrict__ ctl, uint32_t max_steps,
+                                                      uint32_t* __restrict__ sample_hash) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n < N) {
+        if (sample_hash) sample_hash[n] = 2166136261u;
         alive[n] = (int32_t)n;
         rays_t[n] = nears[n];
         weights_sum[n] = 0; depth[n] = 0;
@@ -627,6 +655,7 @@ struct ngp_render_ctx {
     int32_t* staging = nullptr;
     uint32_t* chunk_count = nullptr;
     float* rays_t = nullptr;
+    unsigned long long* coarse = nullptr;   // coarse occupancy bits (<= 8 KB)
     Ctl* ctl = nullptr;          // device [2]
     _Float16* packed = nullptr;  // device
     Ctl* status = nullptr;       // pinned [kRing]
@@ -635,6 +664,8 @@ struct ngp_render_ctx {
 };
 
 static unsigned long long* g_stamps = nullptr;
+static uint32_t* g_sample_hash = nullptr;
+static bool g_coarse_off = false;
 
 static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
     NGP_REQUIRE(m && m->embeddings && m->offsets_host && m->sigma_weights && m->color_weights, "ngp_model: null pointer");
@@ -676,6 +707,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->staging, chunks * 64 * 4) == hipSuccess;
     ok &= hipMalloc(&c->chunk_count, chunks * 4) == hipSuccess;
     ok &= hipMalloc(&c->rays_t, (size_t)max_rays * 4) == hipSuccess;
+    ok &= hipMalloc(&c->coarse, kCoarseMaxBytes) == hipSuccess;
     ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
     ok &= hipHostMalloc(&c->status, kRing * sizeof(Ctl), hipHostMallocDefault) == hipSuccess;
@@ -695,7 +727,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
-    (void)hipFree(c->rays_t); (void)hipFree(c->ctl); (void)hipFree(c->packed);
+    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->ctl); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -724,7 +756,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
     k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
                                                          (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
-    k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps);
+    k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
+                                                 g_sample_hash);
 
     RenderArgs ra = {};
     ra.rays_o = rays_o; ra.rays_d = rays_d; ra.fars = fars; ra.rays_t = ctx->rays_t;
@@ -736,8 +769,19 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
     ra.stamps = g_stamps;
+    ra.sample_hash = g_sample_hash;
 
-    const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab);
+    // coarse occupancy filter: usable when the bitfield is 8-byte aligned and its 1:64 reduction fits the LDS budget
+    const size_t cells = (size_t)model->cascade * model->grid_size * model->grid_size * model->grid_size;
+    const size_t coarse_bytes = cells / 64 / 8;
+    const bool use_coarse = !g_coarse_off && cells % 4096 == 0 && coarse_bytes <= kCoarseMaxBytes && ((uintptr_t)model->density_bitfield & 7) == 0;
+    if (use_coarse) {
+        const uint32_t n_words = (uint32_t)(cells / 64);
+        k_build_coarse<<<div_up(n_words, 256), 256, 0, s>>>((const unsigned long long*)model->density_bitfield, n_words, ctx->coarse);
+        ra.coarse = (const uint32_t*)ctx->coarse;
+        ra.coarse_words = (uint32_t)(coarse_bytes / 4);
+    }
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab) + (use_coarse ? coarse_bytes : 0);
     const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
     static bool attr_set = false;
     if (!attr_set) {
@@ -812,6 +856,16 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
 
 int ngp_debug_set_stamps(unsigned long long* device_buf) {
     g_stamps = device_buf;
+    return NGP_OK;
+}
+
+int ngp_debug_set_sample_hash(uint32_t* device_buf) {
+    g_sample_hash = device_buf;
+    return NGP_OK;
+}
+
+int ngp_debug_disable_march_queue(int off) {
+    g_coarse_off = (off & 2) != 0;
     return NGP_OK;
 }
 

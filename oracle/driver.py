@@ -115,6 +115,7 @@ def oracle_run_cuda(net, rays_o, rays_d, bitfield, bound, cascade, density_scale
     rays_t = nears.copy()
     step, iters, slots, real = 0, 0, 0, 0
     schedule = []
+    sample_hash = np.full(N, 2166136261, np.uint32)   # per-ray FNV-1a over the (dt, deltas[1]) bit patterns, in march order
     while step < max_steps:
         n_alive = rays_alive.shape[0]
         if n_alive <= 0:
@@ -125,6 +126,15 @@ def oracle_run_cuda(net, rays_o, rays_d, bitfield, bound, cascade, density_scale
         xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
         O.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, cascade, grid_size, bitfield,
                      nears, fars, xyzs, dirs, deltas, perturb)
+        with np.errstate(over="ignore"):
+            dview = deltas[:n_alive * n_step].reshape(n_alive, n_step, 2)
+            for k in range(n_step):
+                m = dview[:, k, 0] > 0
+                rr = rays_alive[m]
+                h = sample_hash[rr]
+                h = (h ^ np.ascontiguousarray(dview[m, k, 0]).view(np.uint32)) * np.uint32(16777619)
+                h = (h ^ np.ascontiguousarray(dview[m, k, 1]).view(np.uint32)) * np.uint32(16777619)
+                sample_hash[rr] = h
         sigmas, rgbs = net.forward(xyzs, dirs)
         sigmas = (np.float32(density_scale) * sigmas).astype(np.float32)
         O.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, np.ascontiguousarray(rgbs.astype(np.float32)), deltas,
@@ -136,7 +146,7 @@ def oracle_run_cuda(net, rays_o, rays_d, bitfield, bound, cascade, density_scale
         iters += 1
         slots += n_alive * n_step
     return dict(weights_sum=weights_sum, depth=depth, image=image, nears=nears, fars=fars, iterations=iters, samples_slots=slots,
-                samples_marched=real, schedule=schedule)
+                samples_marched=real, schedule=schedule, sample_hash=sample_hash)
 
 
 def pinhole_rays(pose, intr, H, W):
