@@ -51,9 +51,13 @@ constexpr int kRing = 8;
 // device-side loop state (ping-pong pair); also the pinned status record
 struct Ctl {
     uint32_t n_alive, n_step, step, done;
-    uint32_t iters, last_n_alive, last_n_step, next_chunk;   // next_chunk: work-queue head of the iteration reading this record
+    uint32_t iters, last_n_alive, last_n_step, pad;
     unsigned long long samples_marched, samples_slots;
 };
+// work-queue heads: one per shard (chunk c belongs to shard c & 7), each on its own 128-byte line, two sets (ping-pong with Ctl)
+struct QueueHeads { uint32_t head[8][32]; };
+
+constexpr int kStatShards = 64;   // sample counters are sharded: a single hot atomic serialises at ~90 ops/us chip-wide
 
 // per-level table staged in LDS (16 levels)
 struct LevelTab {
@@ -343,7 +347,9 @@ struct RenderArgs {
     const int32_t* alive_in;
     int32_t* staging;                 // [chunks*64] chunk-local compacted survivors
     uint32_t* chunk_count;            // [chunks]
-    Ctl* ctl;                         // state read by this iteration (+ its work-queue head)
+    Ctl* ctl;                         // state read by this iteration
+    QueueHeads* heads;                // its work-queue heads (zeroed by the previous k_render_compact / k_render_init)
+    unsigned long long* stat_shards;  // [kStatShards] marched-sample counters (summed by k_render_compact)
     const uint8_t* bitfield;
     uint32_t cascade, grid_size, max_steps, perturb;
     float dt_gamma;
@@ -388,12 +394,22 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         ts0 = ts1;                                                                      \
     }
 
-    // every wave pulls 64-ray chunks from a device-side queue: no inter-wave coupling, no tail imbalance
+    // every wave pulls 64-ray chunks from a device-side queue: no inter-wave coupling, no tail imbalance.  The queue is
+    // sharded up to 8 ways (chunk c lives in shard c % n_shards, heads on separate cache lines; a single hot atomic serialises at ~90
+    // ops/us chip-wide); a workgroup serves the shard of its XCD group.  Shards hold equal work, so there is no stealing.
+    const uint32_t n_shards = gridDim.x < 8u ? gridDim.x : 8u;   // every shard must have a workgroup serving it
+    const uint32_t shard = blockIdx.x % n_shards;
+    unsigned long long wave_total = 0;
     for (;;) {
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(&ra.ctl->next_chunk, 1u);
-        chunk = __builtin_amdgcn_readfirstlane(chunk);
-        if (chunk >= n_chunks) break;
+        uint32_t chunk = 0xFFFFFFFFu;
+        {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(&ra.heads->head[shard][0], 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            const uint32_t cand = k * n_shards + shard;
+            if (cand < n_chunks) chunk = cand;
+        }
+        if (chunk == 0xFFFFFFFFu) break;
         if (ra.stamps) ts0 = __builtin_amdgcn_s_memtime();
 
         const uint32_t entry = chunk * 64 + lane;
@@ -551,10 +567,8 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         const unsigned long long ball = __ballot(survive);
         const uint32_t rank_in_wave = (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
         if (survive) ra.staging[(size_t)chunk * 64 + rank_in_wave] = ray;
-        if (lane == 0) {
-            ra.chunk_count[chunk] = (uint32_t)__popcll(ball);
-            if (wave_samples) atomicAdd(&ra.ctl->samples_marched, (unsigned long long)wave_samples);
-        }
+        if (lane == 0) ra.chunk_count[chunk] = (uint32_t)__popcll(ball);
+        wave_total += wave_samples;
         // padding rows of the reference's [M_padded] tensors (M += 128 - M % 128), written by the last chunk's wave
         if (ra.last_sigmas && chunk == n_chunks - 1) {
             for (uint32_t i = lane; i < 128; i += 64) {
@@ -566,18 +580,20 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         NGP_STAMP(3)
     }
 #undef NGP_STAMP
+    if (lane == 0 && wave_total) atomicAdd(&ra.stat_shards[(blockIdx.x * kWaves + wid) % kStatShards], wave_total);
 }
 
 // stitch chunk survivor lists -> next alive list; advance the reference's schedule (renderer.py:347-373).
 // One 256-thread block per 8 chunks (512 alive entries): wave w copies chunks 2w, 2w+1 of its block.
 __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ cur, Ctl* __restrict__ nxt, const int32_t* __restrict__ staging,
                                                          const uint32_t* __restrict__ chunk_count, int32_t* __restrict__ alive_out, uint32_t N,
-                                                         uint32_t max_steps) {
+                                                         uint32_t max_steps, const unsigned long long* __restrict__ stat_shards,
+                                                         QueueHeads* __restrict__ nxt_heads) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t local_off[9];
     const Ctl c = *cur;
     if (c.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { Ctl n = c; n.next_chunk = 0; *nxt = n; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = c;
         return;
     }
     const uint32_t n_chunks = (c.n_alive + 63) / 64;
@@ -607,8 +623,12 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         const uint32_t cnt = local_off[ci + 1] - local_off[ci];
         if (lane < cnt) alive_out[prefix + local_off[ci] + lane] = staging[(size_t)(first + ci) * 64 + lane];
     }
+    unsigned long long marched = threadIdx.x < (uint32_t)kStatShards ? stat_shards[threadIdx.x] : 0ull;   // kStatShards == 64: wave 0
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) marched += __shfl_down(marched, off, 64);
     if (g == n_blocks - 1 && threadIdx.x == 0) {
         Ctl n = c;
+        n.samples_marched = marched;
         n.last_n_alive = c.n_alive;
         n.last_n_step = c.n_step;
         n.iters = c.iters + 1;
@@ -618,16 +638,19 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         uint32_t ns = n.n_alive ? N / n.n_alive : 8;
         n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
         n.done = (n.n_alive == 0 || n.step >= max_steps) ? 1 : 0;
-        n.next_chunk = 0;
         *nxt = n;
+        for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
     }
 }
 
 __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __restrict__ nears, float* __restrict__ rays_t,
                                                       int32_t* __restrict__ alive, float* __restrict__ weights_sum, float* __restrict__ depth,
                                                       float* __restrict__ image, Ctl* __restrict__ ctl, uint32_t max_steps,
-                                                      uint32_t* __restrict__ sample_hash) {
+                                                      uint32_t* __restrict__ sample_hash, unsigned long long* __restrict__ stat_shards,
+                                                      QueueHeads* __restrict__ heads) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n < (uint32_t)kStatShards) stat_shards[n] = 0ull;
+    if (n < 16) heads[n >> 3].head[n & 7][0] = 0;
     if (n < N) {
         if (sample_hash) sample_hash[n] = 2166136261u;
         alive[n] = (int32_t)n;
@@ -657,6 +680,8 @@ struct ngp_render_ctx {
     float* rays_t = nullptr;
     unsigned long long* coarse = nullptr;   // coarse occupancy bits (<= 8 KB)
     Ctl* ctl = nullptr;          // device [2]
+    unsigned long long* stat_shards = nullptr;
+    QueueHeads* heads = nullptr;  // device [2]
     _Float16* packed = nullptr;  // device
     Ctl* status = nullptr;       // pinned [kRing]
     hipEvent_t ev[kRing];
@@ -709,6 +734,8 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->rays_t, (size_t)max_rays * 4) == hipSuccess;
     ok &= hipMalloc(&c->coarse, kCoarseMaxBytes) == hipSuccess;
     ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
+    ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
+    ok &= hipMalloc(&c->heads, 2 * sizeof(QueueHeads)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
     ok &= hipHostMalloc(&c->status, kRing * sizeof(Ctl), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < kRing; i++) ok &= hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
@@ -727,7 +754,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
-    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->ctl); (void)hipFree(c->packed);
+    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -757,14 +784,14 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
                                                          (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
     k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
-                                                 g_sample_hash);
+                                                 g_sample_hash, ctx->stat_shards, ctx->heads);
 
     RenderArgs ra = {};
     ra.rays_o = rays_o; ra.rays_d = rays_d; ra.fars = fars; ra.rays_t = ctx->rays_t;
     ra.weights_sum = weights_sum; ra.depth = depth; ra.image = image;
     ra.last_sigmas = last_sigmas; ra.last_rgbs = last_rgbs;
     if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
-    ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count;
+    ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count; ra.stat_shards = ctx->stat_shards;
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
@@ -806,13 +833,14 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         const uint32_t blocks = want_blocks < max_blocks ? want_blocks : max_blocks;
         ra.alive_in = ctx->alive[cur];
         ra.ctl = ctx->ctl + cur;
+        ra.heads = ctx->heads + cur;
         {
             ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
             if (generic) k_render_iter<true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
             else k_render_iter<false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
-                                                           ctx->alive[cur ^ 1], N, max_steps);
+                                                           ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1));
         (void)hipMemcpyAsync(&ctx->status[launched % kRing], ctx->ctl + (cur ^ 1), sizeof(Ctl), hipMemcpyDeviceToHost, s);
         (void)hipEventRecord(ctx->ev[launched % kRing], s);
         launched++;

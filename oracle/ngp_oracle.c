@@ -828,6 +828,15 @@ ORACLE_API void oracle_mlp_f32(const float* inputs, const float* weights, uint32
     }
 }
 
+ORACLE_API void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORACLE_API int oracle_num_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

@@ -69,6 +69,23 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def usable_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota (containers)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(C.c_int(int(n)))
+    return num_threads()
+
+
 # ---------------------------------------------------------------- raymarching
 def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
     lib().oracle_near_far_from_aabb(_p(rays_o), _p(rays_d), _p(aabb), u32(N), f32(min_near), _p(nears), _p(fars))
