@@ -448,11 +448,12 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             const uint32_t want = (n_step - s0) < (uint32_t)kCh ? (n_step - s0) : (uint32_t)kCh;
             // ---- 1. march (raymarching.cu:757-813), lane = ray.  A ray whose compositing already stopped is not marched
             //         further unless the caller asked for the reference's last-iteration tensors.
-            uint32_t cnt = 0;
+            uint32_t cnt = 0, n_probes = 0;
             const bool do_march = active && (running || ra.last_sigmas != nullptr);
             if (do_march) {
                 float x, y, z, dt;
                 while (t_march < far && cnt < want) {
+                    n_probes++;
                     if (dda.probe(t_march, x, y, z, dt, coarse)) {
                         S.t[lane * kCh + cnt] = t_march;
                         S.dt[lane * kCh + cnt] = dt;
@@ -466,6 +467,12 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                         cnt++;
                     }
                 }
+            }
+            if (ra.stamps) {   // diagnostics: lane utilisation of the march (sum and per-wave max of DDA probes)
+                uint32_t mx = n_probes, sm = n_probes;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64)); sm += __shfl_xor(sm, off, 64); }
+                if (lane == 0) { atomicAdd(ra.stamps + 4, (unsigned long long)mx); atomicAdd(ra.stamps + 5, (unsigned long long)sm); atomicAdd(ra.stamps + 6, 1ull); }
             }
             if (!__any(cnt != 0)) {
                 // nothing to evaluate in this sub-pass for the whole wave

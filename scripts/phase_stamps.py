@@ -19,3 +19,4 @@ with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
     torch.cuda.synchronize(); lib.ngp_debug_set_stamps(None)
 b = buf.cpu().tolist(); tot = sum(b[:4])
 for n, v in zip(['march', 'encode+mlp tiles', 'composite', 'compaction+barrier'], b[:4]): print(f'{n:22s} {v:16d} {100*v/tot:6.2f} %')
+print(f"march passes {b[6]}: mean probes per lane-pass {b[5]/max(1,b[6])/64:.2f}, mean of per-wave max {b[4]/max(1,b[6]):.2f}  -> lane utilisation {b[5]/max(1,64*b[4]):.3f}")
