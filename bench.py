@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--cpu-stride", type=int, default=16, help="cpu_baseline renders rays[::stride] of view 0")
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
+    p.add_argument("--no-last", action="store_true", help="do not materialise the last iteration's sigmas/rgbs tensors")
     return p.parse_args()
 
 
@@ -67,6 +68,8 @@ def main():
     H = W = args.size
     sc = StonehengeScene(H=H, W=W, bound=2)
     model = sc.build_model(dev)              # FFMLP backbone, cuda_ray=True, fused path on
+    if args.no_last:
+        model.return_last_tensors = False
     poses = torch.from_numpy(sc.poses).to(dev)
     n_views = poses.shape[0]
     intr = sc.intrinsics

@@ -182,6 +182,23 @@ struct Dda {
         return (int)clampf(s, 0.0f, Hm1);
     }
 
+    // True when the occupancy cell containing the march position at t is empty (same cell arithmetic as probe(); the coarse
+    // bits answer most queries from LDS).  Used only to PREDICT that a ray's next march starts with a skip through empty space.
+    __device__ __forceinline__ bool coarse_empty_at(float t, const uint32_t* coarse) const {
+        const float x = clampf(fmaf(t, dx, ox), -bound, bound);
+        const float y = clampf(fmaf(t, dy, oy), -bound, bound);
+        const float z = clampf(fmaf(t, dz, oz), -bound, bound);
+        const float dt = const_dt ? dt_min : clampf(t * dt_gamma, dt_min, dt_max);
+        const int lp = mip_from_pos(x, y, z), ld = const_dt ? level_dt0 : mip_from_dt(dt);
+        const int level = lp > ld ? lp : ld;
+        const float pw = (float)(1 << level);
+        const float mip_rbound = pw <= bound ? __uint_as_float((uint32_t)(127 - level) << 23) : rbound;
+        const uint32_t index = (uint32_t)((float)level * H3f + (float)morton3D_cell((uint32_t)cell(x, mip_rbound), (uint32_t)cell(y, mip_rbound),
+                                                                                    (uint32_t)cell(z, mip_rbound)));
+        if (((coarse[index >> 11] >> ((index >> 6) & 31u)) & 1u) == 0) return true;
+        return (grid[index >> 3] & (1u << (index & 7u))) == 0;   // the cell itself is empty: the next march starts with a skip
+    }
+
     // Probe at t. Occupied: returns true with x,y,z,dt set (caller advances t += dt).
     // Empty: t is advanced past the next voxel boundary (:386-403) and false is returned.
     // `coarse` (optional, LDS): one bit per 64 consecutive cells of the Morton-ordered bitfield (= a 4x4x4 block); a clear

@@ -58,6 +58,7 @@ class NeRFRenderer(nn.Module):
         self.density_thresh = density_thresh
         self.bg_radius = bg_radius
         self.fused = True  # MI355X extension: allow the fused render entry point in eval-mode run_cuda
+        self.return_last_tensors = True  # fused path: also return the last iteration's sigmas / rgbs (renderer.py:383-384)
 
         aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
         self.register_buffer("aabb_train", aabb_train)
@@ -230,7 +231,8 @@ class NeRFRenderer(nn.Module):
         else:
             fm = self.fused_model() if self.fused else None
             if fm is not None and not torch.is_grad_enabled():
-                weights_sum, depth, image, sigmas, rgbs = fm.render(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb)
+                weights_sum, depth, image, sigmas, rgbs = fm.render(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb,
+                                                                    want_last=self.return_last_tensors)
                 self.last_render_stats = fm.last_stats
             else:
                 weights_sum, depth, image, sigmas, rgbs = self._march_composite_loop(rays_o, rays_d, nears, fars, dt_gamma,
