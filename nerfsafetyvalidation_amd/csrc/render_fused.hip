@@ -344,6 +344,8 @@ struct RenderArgs {
     float *weights_sum, *depth, *image;
     float *last_sigmas, *last_rgbs;   // optional dump of the iteration's slot-major outputs
     float pad_sigma, pad_r, pad_g, pad_b;
+    float4* dump_rec;                 // [N][8] per-RAY records (sigma, r, g, b) of the current iteration, used instead of the slot-major rows
+    uint32_t* dump_iter;              // [N]    when the alive list is regrouped (sort_slow): k_dump_gather restores the reference's row order
     const int32_t* alive_in;
     int32_t* staging;                 // [chunks*64] chunk-local compacted survivors
     uint32_t* chunk_count;            // [chunks] survivors per chunk: fast | slow << 16 (see sort_slow)
@@ -367,6 +369,19 @@ struct WaveSlab {  // per-wave LDS: kCh march steps of 64 rays
     uint16_t list[kSlots];
     float od[64][6];
 };
+
+// one row of the reference's last-iteration tensors (renderer.py:383-384): slot-major row (alive list in reference order) or,
+// when the alive list is regrouped, a per-ray record that k_dump_gather sorts back into reference order after the loop
+__device__ __forceinline__ void dump_row(const RenderArgs& ra, uint32_t entry, int32_t ray, uint32_t n_step, uint32_t k, float sg, float r,
+                                         float g, float b) {
+    if (ra.dump_rec) {
+        ra.dump_rec[(size_t)ray * 8 + k] = make_float4(sg, r, g, b);
+    } else {
+        const size_t row = (size_t)entry * n_step + k;
+        ra.last_sigmas[row] = sg;
+        ra.last_rgbs[row * 3] = r; ra.last_rgbs[row * 3 + 1] = g; ra.last_rgbs[row * 3 + 2] = b;
+    }
+}
 
 template <bool GENERIC>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
@@ -479,11 +494,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                 // nothing to evaluate in this sub-pass for the whole wave
                 if (running && cnt < want) running = false;
                 if (ra.last_sigmas && active)
-                    for (uint32_t k = 0; k < want; k++) {
-                        const size_t row = (size_t)entry * n_step + s0 + k;
-                        ra.last_sigmas[row] = ra.pad_sigma;
-                        ra.last_rgbs[row * 3] = ra.pad_r; ra.last_rgbs[row * 3 + 1] = ra.pad_g; ra.last_rgbs[row * 3 + 2] = ra.pad_b;
-                    }
+                    for (uint32_t k = 0; k < want; k++) dump_row(ra, entry, ray, n_step, s0 + k, ra.pad_sigma, ra.pad_r, ra.pad_g, ra.pad_b);
                 if (!ra.last_sigmas && !__any(running)) break;
                 continue;
             }
@@ -550,13 +561,13 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             }
             if (ra.last_sigmas && active) {
                 for (uint32_t k = 0; k < want; k++) {
-                    const size_t row = (size_t)entry * n_step + s0 + k;
                     const uint32_t slot = lane * kCh + k;
-                    const bool have = k < cnt;
-                    ra.last_sigmas[row] = have ? S.sig[slot] : ra.pad_sigma;
-                    ra.last_rgbs[row * 3] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.rg[slot] & 0xffffu)) : ra.pad_r;
-                    ra.last_rgbs[row * 3 + 1] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.rg[slot] >> 16)) : ra.pad_g;
-                    ra.last_rgbs[row * 3 + 2] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(S.b[slot] & 0xffffu)) : ra.pad_b;
+                    if (k < cnt)
+                        dump_row(ra, entry, ray, n_step, s0 + k, S.sig[slot], (float)__builtin_bit_cast(_Float16, (uint16_t)(S.rg[slot] & 0xffffu)),
+                                 (float)__builtin_bit_cast(_Float16, (uint16_t)(S.rg[slot] >> 16)),
+                                 (float)__builtin_bit_cast(_Float16, (uint16_t)(S.b[slot] & 0xffffu)));
+                    else
+                        dump_row(ra, entry, ray, n_step, s0 + k, ra.pad_sigma, ra.pad_r, ra.pad_g, ra.pad_b);
                 }
             }
             NGP_STAMP(2)
@@ -585,7 +596,8 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         if (lane == 0) ra.chunk_count[chunk] = (uint32_t)__popcll(ball_f) | ((uint32_t)__popcll(ball_s) << 16);
         wave_total += wave_samples;
         // padding rows of the reference's [M_padded] tensors (M += 128 - M % 128), written by the last chunk's wave
-        if (ra.last_sigmas && chunk == n_chunks - 1) {
+        if (ra.dump_iter && active) ra.dump_iter[ray] = ctl.iters;
+        if (ra.last_sigmas && !ra.dump_rec && chunk == n_chunks - 1) {
             for (uint32_t i = lane; i < 128; i += 64) {
                 const size_t row = (size_t)n_alive * n_step + i;
                 ra.last_sigmas[row] = ra.pad_sigma;
@@ -699,6 +711,74 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
     }
 }
 
+// ---- restoring the reference's row order of the last iteration's tensors when the alive list was regrouped -------------
+// The reference's alive list is always ascending in ray id (stable compaction of arange(N)), so row r of its last
+// iteration belongs to the r-th smallest ray id that was alive then.  Three small launches after the loop: per-block counts
+// of rays stamped with the last iteration, a one-block scan, and the scatter of the per-ray records.
+__global__ void __launch_bounds__(256) k_dump_count(const uint32_t* __restrict__ dump_iter, uint32_t N, uint32_t last_iter,
+                                                     uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t ws[4];
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    const bool f = n < N && dump_iter[n] == last_iter;
+    const uint32_t c = (uint32_t)__popcll(__ballot(f));
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ void __launch_bounds__(1024) k_dump_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < nblocks; start += 1024) {
+        const uint32_t i = start + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += o;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wid; w++) wave_off += wave_tot[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_dump_gather(const uint32_t* __restrict__ dump_iter, const float4* __restrict__ rec, uint32_t N,
+                                                      uint32_t last_iter, uint32_t n_alive, uint32_t n_step, const uint32_t* __restrict__ block_off,
+                                                      float* __restrict__ last_sigmas, float* __restrict__ last_rgbs, float ps, float pr, float pg,
+                                                      float pb) {
+    __shared__ uint32_t ws[4];
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool f = n < N && dump_iter[n] == last_iter;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) ws[wid] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t rank = block_off[blockIdx.x] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wid; w++) rank += ws[w];
+    if (f) {
+        for (uint32_t k = 0; k < n_step; k++) {
+            const float4 v = rec[(size_t)n * 8 + k];
+            const size_t row = (size_t)rank * n_step + k;
+            last_sigmas[row] = v.x;
+            last_rgbs[row * 3] = v.y; last_rgbs[row * 3 + 1] = v.z; last_rgbs[row * 3 + 2] = v.w;
+        }
+    }
+    if (n < 128) {   // padding rows (M += 128 - M % 128)
+        const size_t row = (size_t)n_alive * n_step + n;
+        last_sigmas[row] = ps;
+        last_rgbs[row * 3] = pr; last_rgbs[row * 3 + 1] = pg; last_rgbs[row * 3 + 2] = pb;
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -710,6 +790,8 @@ struct ngp_render_ctx {
     uint32_t* chunk_count = nullptr;
     float* rays_t = nullptr;
     unsigned long long* coarse = nullptr;   // coarse occupancy bits (<= 8 KB)
+    float4* dump_rec = nullptr;             // lazily allocated: [max_rays][8]
+    uint32_t* dump_iter = nullptr;          // [max_rays]
     Ctl* ctl = nullptr;          // device [2]
     unsigned long long* stat_shards = nullptr;
     QueueHeads* heads = nullptr;  // device [2]
@@ -786,7 +868,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
-    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
+    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -828,7 +910,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
     ra.stamps = g_stamps;
-    ra.sort_slow = (perturb == 0 && last_sigmas == nullptr && !g_sort_off) ? 1u : 0u;   // needs the coarse filter; checked below
+    ra.sort_slow = (perturb == 0 && !g_sort_off) ? 1u : 0u;   // needs the coarse filter; checked below
     ra.sample_hash = g_sample_hash;
 
     // coarse occupancy filter: usable when the bitfield is 8-byte aligned and its 1:64 reduction fits the LDS budget
@@ -842,6 +924,19 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.coarse_words = (uint32_t)(coarse_bytes / 4);
     } else {
         ra.sort_slow = 0;
+    }
+    if (ra.sort_slow && last_sigmas) {
+        // regrouped alive list + last-iteration tensors requested: collect per-ray records, restore the row order afterwards
+        if (!ctx->dump_rec) {
+            if (hipMalloc(&ctx->dump_rec, (size_t)ctx->max_rays * 8 * sizeof(float4)) != hipSuccess ||
+                hipMalloc(&ctx->dump_iter, (size_t)ctx->max_rays * 4) != hipSuccess) {
+                set_error("render_rays: cannot allocate the per-ray record buffer");
+                return NGP_ENODEVICE;
+            }
+        }
+        (void)hipMemsetAsync(ctx->dump_iter, 0xff, (size_t)N * 4, s);
+        ra.dump_rec = ctx->dump_rec;
+        ra.dump_iter = ctx->dump_iter;
     }
     const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab) + (use_coarse ? coarse_bytes : 0);
     const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -894,6 +989,13 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             set_error("render_rays: iteration bound exceeded");
             return NGP_ELAUNCH;
         }
+    }
+    if (ra.dump_rec && last.iters > 0) {
+        const uint32_t nb = div_up(N, 256);
+        k_dump_count<<<nb, 256, 0, s>>>(ctx->dump_iter, N, last.iters - 1, ctx->chunk_count);
+        k_dump_scan<<<1, 1024, 0, s>>>(ctx->chunk_count, nb);
+        k_dump_gather<<<nb, 256, 0, s>>>(ctx->dump_iter, ctx->dump_rec, N, last.iters - 1, last.last_n_alive, last.last_n_step, ctx->chunk_count,
+                                         last_sigmas, last_rgbs, ra.pad_sigma, ra.pad_r, ra.pad_g, ra.pad_b);
     }
     rc = check_launch("render_rays");
     if (rc) return rc;
