@@ -233,6 +233,17 @@ NGP_API int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const f
 NGP_API int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas,
                         float* rgbs, ngp_stream_t stream);
 
+/* NeRFRenderer.run (nerf/renderer.py:125-258) for upsample_steps == 0 and perturb == False with the fp16 network: T uniform
+ * samples per ray between nears and fars (lin = the T values of torch.linspace(0, 1, T), device memory), hash grid + sigma net
+ * on every sample, transmittance scan, colour net where weight > 1e-4, and the per-ray sums.  Outputs: weights_sum [N],
+ * depth [N] (sum of weights * clamp((z - near) / (far - near), 0, 1)), image [N,3] (BEFORE the background mix),
+ * aggregated_density [N]; for rays >= dump_begin also the per-sample sigmas [(N - dump_begin) * T] and
+ * rgbs [(N - dump_begin) * T, 3] (the reference returns those of the last ray chunk only); both may be NULL. */
+NGP_API int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears,
+                       const float* fars, uint32_t N, uint32_t T, const float* lin, float* weights_sum, float* depth,
+                       float* image, float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs,
+                       ngp_stream_t stream);
+
 /* Diagnostics: when a device buffer of >= 8 uint64 is set, k_render_iter adds per-phase wave-cycle sums
  * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier).  NULL (default) = no
  * stamp instruction executes. */

@@ -150,6 +150,23 @@ class FusedModel:
             sigmas, rgbs = last_s[:M], last_c[:M]
         return weights_sum, depth, image, sigmas, rgbs
 
+    def render_uniform(self, rays_o, rays_d, nears, fars, num_steps, dump_begin):
+        """NeRFRenderer.run without upsampling for ALL rays in one launch -> weights_sum, depth, image (no background), aggregated
+        density [N] and the per-sample sigmas [(N-dump_begin)*T, 1] / rgbs [N-dump_begin, T, 3] of the rays >= dump_begin"""
+        N, T, dev = rays_o.shape[0], int(num_steps), rays_o.device
+        lin = torch.linspace(0.0, 1.0, T, device=dev)
+        out = [torch.empty(N, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
+               torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)]
+        n_dump = N - dump_begin
+        sigmas = torch.empty(n_dump * T, 1, dtype=torch.float32, device=dev)
+        rgbs = torch.empty(n_dump, T, 3, dtype=torch.float32, device=dev)
+        m = self._struct(None)
+        lib = _lib.lib()
+        _lib.check(lib.ngp_render_uniform(C.byref(m), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()), _lib.ptr(fars.contiguous()),
+                                          N, T, _lib.ptr(lin), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
+                                          dump_begin, _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.stream()), "render_uniform")
+        return out[0], out[1], out[2], out[3], sigmas, rgbs
+
     def __del__(self):
         try:
             if self._ctx is not None:

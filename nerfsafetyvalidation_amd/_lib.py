@@ -71,6 +71,7 @@ SIGNATURES = {
     "ngp_render_rays": [_vp, C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                         C.POINTER(C.c_float), C.POINTER(RenderStats), _int, _vp],
     "ngp_network_forward": [C.POINTER(ModelStruct), _vp, _vp, _u32, _vp, _vp, _vp],
+    "ngp_render_uniform": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
     "ngp_debug_set_stamps": [_vp],
     "ngp_debug_set_sample_hash": [_vp],
     "ngp_debug_disable_march_queue": [_int],

@@ -183,9 +183,10 @@ __device__ __forceinline__ void sh4_quarter(uint32_t q, float x, float y, float 
     }
 }
 
+// density half: hash-grid encode + sigma net.  Returns sigma (meaningful in q == 0) and the sigma-net outputs 4q..4q+3 as fp16.
 template <bool GENERIC>
-__device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
-                                         float dx, float dy, float dz, float& sigma, float& cr, float& cg, float& cb) {
+__device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
+                                            float& sigma, _Float16 (&s16)[4]) {
     const uint32_t q = lane >> 4;
     // encoder input: (x + bound) / (2 bound)  (gridencoder/grid.py:144).  torch evaluates a division by a Python scalar on
     // the GPU as a multiplication with the fp32 reciprocal; identical to the division whenever 2*bound is a power of two.
@@ -252,11 +253,16 @@ __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds
     mlp_in(Ws, lane, feat, h);
     for (uint32_t k = 0; k < na.sig_mm; k++) mlp_hidden(Ws + 256 + k * 512, lane, h);
     const f32x4 so = mlp_out(Ws + 256 + na.sig_mm * 512, lane, h);
-    _Float16 s16[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) s16[r] = (_Float16)so[r];
     sigma = expf((float)s16[0]);  // trunc_exp forward (activation.py:8-10), meaningful in q == 0
+}
 
+// colour half: SH degree 4 + geo_feat -> colour net -> fp16 sigmoid (results in q == 0)
+__device__ __forceinline__ void net_color(const NetArgs& na, const _Float16* Wlds, uint32_t lane, float dx, float dy, float dz,
+                                          const _Float16 (&s16)[4], float& cr, float& cg, float& cb) {
+    const uint32_t q = lane >> 4;
+    half8 h[2];
     // ---- colour net input: [SH(16) | geo_feat(15) | 0] in the permuted k order of perm_color
     float sh[4];
     sh4_quarter(q, dx, dy, dz, sh);
@@ -275,6 +281,14 @@ __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds
     cr = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[0])));
     cg = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[1])));
     cb = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[2])));
+}
+
+template <bool GENERIC>
+__device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
+                                         float dx, float dy, float dz, float& sigma, float& cr, float& cg, float& cb) {
+    _Float16 s16[4];
+    net_density<GENERIC>(na, Wlds, lt, lane, x, y, z, sigma, s16);
+    net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
 }
 
 // stage packed weights + level table into LDS (all threads of the block)
@@ -322,6 +336,96 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
             rgbs[(size_t)m * 3] = r;
             rgbs[(size_t)m * 3 + 1] = g;
             rgbs[(size_t)m * 3 + 2] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NeRFRenderer.run, uniform sampling without upsampling (nerf/renderer.py:125-258): the path validate.py -O executes
+// (cuda_ray = False, num_steps = 512).  One wave walks one ray 16 samples at a time: positions from the linspace table,
+// fused hash-grid + sigma net, in-wave transmittance scan (alphas * cumprod(1 - alphas + 1e-15), :206-210), colour net only
+// for tiles that contain a sample with weight > 1e-4 (the reference's masked colour query, :216-218), running sums of
+// weights, depth, colour and weights * sigma.  None of the reference's [N, T, *] intermediates exists in memory; the
+// per-sample sigmas / rgbs it returns for the LAST ray chunk are written only for rays >= dump_begin.
+// ------------------------------------------------------------------------------------------
+template <bool GENERIC>
+__global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, const float* __restrict__ nears,
+                                                           const float* __restrict__ fars, uint32_t N, uint32_t T,
+                                                           const float* __restrict__ lin, float* __restrict__ weights_sum,
+                                                           float* __restrict__ depth, float* __restrict__ image,
+                                                           float* __restrict__ aggregated_density, uint32_t dump_begin,
+                                                           float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t ray = wave; ray < N; ray += n_waves) {
+        const float ox = rays_o[(size_t)ray * 3], oy = rays_o[(size_t)ray * 3 + 1], oz = rays_o[(size_t)ray * 3 + 2];
+        const float dx = rays_d[(size_t)ray * 3], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
+        const float near = nears[ray], far = fars[ray];
+        const float span = far - near;
+        const float sample_dist = span / (float)T;                                  // :153
+        const bool dump = sigmas != nullptr && ray >= dump_begin;
+        float carry = 1.0f;                                                          // cumprod of (1 - alpha + 1e-15) over earlier tiles
+        float a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;             // per-lane partial sums (lanes 0..15)
+        for (uint32_t i0 = 0; i0 < T; i0 += 16) {
+            const uint32_t idx = i0 + c;
+            const bool valid = idx < T;
+            const uint32_t ii = valid ? idx : T - 1;
+            const float zv = near + span * lin[ii];                                  // :150 (mul, then add: eager torch does not fuse)
+            const float x = clampf(ox + dx * zv, aabb_lo, aabb_hi);                  // :159-160
+            const float y = clampf(oy + dy * zv, aabb_lo, aabb_hi);
+            const float z = clampf(oz + dz * zv, aabb_lo, aabb_hi);
+            float sigma;
+            _Float16 s16[4];
+            net_density<GENERIC>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+            // ---- lanes 0..15 hold sigma of samples i0..i0+15 (the other quarters compute along with them; only lane < 16 results are used)
+            const float z_next = (ii + 1 < T) ? near + span * lin[ii + 1] : 0.0f;
+            const float delta = (ii + 1 < T) ? z_next - zv : sample_dist;           // :206-207
+            const float alpha = valid ? 1.0f - expf(((-delta) * na.density_scale) * sigma) : 0.0f;   // :208
+            const float p = (1.0f - alpha) + 1e-15f;                                 // :209
+            float incl = p;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float o = __shfl_up(incl, off, 16);
+                if (c >= (uint32_t)off) incl *= o;
+            }
+            const float excl_in_tile = __shfl_up(incl, 1, 16);
+            const float Tr = carry * (c == 0 ? 1.0f : excl_in_tile);
+            const float w = alpha * Tr;                                              // :210
+            const bool masked = valid && w > 1e-4f;                                  // :216
+            float cr = 0, cg = 0, cb = 0;
+            if (__ballot(masked && lane < 16) != 0ull) {
+                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                if (!masked) { cr = 0; cg = 0; cb = 0; }
+            }
+            if (lane < 16 && valid) {
+                a_ws += w;
+                const float qz = (zv - near) / span;                                 // :227; 0/0 = NaN for rays that miss the box and
+                a_dep += w * (qz != qz ? qz : fminf(1.0f, fmaxf(0.0f, qz)));         // torch.clamp keeps the NaN, as the reference does
+                a_r += w * cr; a_g += w * cg; a_b += w * cb;                         // :231
+                a_agg += w * sigma;                                                  // :244
+                if (dump) {
+                    const size_t row = (size_t)(ray - dump_begin) * T + idx;
+                    sigmas[row] = sigma;
+                    rgbs[row * 3] = cr; rgbs[row * 3 + 1] = cg; rgbs[row * 3 + 2] = cb;
+                }
+            }
+            carry *= __shfl(incl, 15, 16);
+            // everything further down the ray is weighted by <= carry: below fp32 resolution of the O(1) sums
+            if (!dump && carry < 1e-10f) break;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            a_ws += __shfl_xor(a_ws, off, 16); a_dep += __shfl_xor(a_dep, off, 16); a_agg += __shfl_xor(a_agg, off, 16);
+            a_r += __shfl_xor(a_r, off, 16); a_g += __shfl_xor(a_g, off, 16); a_b += __shfl_xor(a_b, off, 16);
+        }
+        if (lane == 0) {
+            weights_sum[ray] = a_ws; depth[ray] = a_dep; aggregated_density[ray] = a_agg;
+            image[(size_t)ray * 3] = a_r; image[(size_t)ray * 3 + 1] = a_g; image[(size_t)ray * 3 + 2] = a_b;
         }
     }
 }
@@ -1033,6 +1137,45 @@ int ngp_debug_disable_march_queue(int off) {
     g_coarse_off = (off & 2) != 0;
     g_sort_off = (off & 4) != 0;
     return NGP_OK;
+}
+
+int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N,
+                       uint32_t T, const float* lin, float* weights_sum, float* depth, float* image, float* aggregated_density,
+                       uint32_t dump_begin, float* sigmas, float* rgbs, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && nears && fars && lin && weights_sum && depth && image && aggregated_density, "render_uniform: null pointer");
+    NGP_REQUIRE((sigmas == nullptr) == (rgbs == nullptr), "render_uniform: sigmas and rgbs must both be given or both NULL");
+    NGP_REQUIRE(T >= 1, "render_uniform: num_steps must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    static _Float16* packed = nullptr;  // setup-time scratch, one per process
+    if (!packed && hipMalloc(&packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) != hipSuccess) {
+        set_error("render_uniform: hipMalloc failed");
+        return NGP_ENODEVICE;
+    }
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, nullptr, packed, na, lv);
+    if (rc) return rc;
+    const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
+    k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
+                                                         (const _Float16*)model->color_weights, na.col_mm, packed);
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    uint32_t blocks = div_up(N, 4);
+    if (blocks > 1024) blocks = 1024;   // 4 workgroups of 4 waves per CU; each wave strides over rays
+    ProfScope prof("render_uniform", s, (double)N * T);
+    if (needs_generic(lv))
+        k_render_uniform<true><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                        dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    else
+        k_render_uniform<false><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image,
+                                                         aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    return check_launch("render_uniform");
 }
 
 int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, float* rgbs,

@@ -364,10 +364,39 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
 
     # ------------------------------------------------------------------ chunked entry point (renderer.py:549-588)
+    def _aabb_is_cube(self):
+        """the fused kernel clips sample positions to [-bound, bound]^3; a user-edited aabb takes the operator path"""
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        key = (aabb.data_ptr(), aabb._version)
+        if getattr(self, "_aabb_key", None) != key:
+            self._aabb_key, self._aabb_cube = key, aabb.tolist() == [-self.bound] * 3 + [self.bound] * 3
+        return self._aabb_cube
+
+    def _render_staged_fused(self, fm, rays_o, rays_d, max_ray_batch, num_steps=128, bg_color=None, **kwargs):
+        """staged render through `run` for the whole frame in ONE fused launch (ngp_render_uniform); same result dict as the chunk
+        loop below, including the last-chunk-only rgbs / sigmas (F8)."""
+        B, N = rays_o.shape[:2]
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        depth, image, agg = [], [], []
+        for b in range(B):
+            o, d = rays_o[b].contiguous().view(-1, 3).float(), rays_d[b].contiguous().view(-1, 3).float()
+            nears, fars = raymarching.near_far_from_aabb(o, d, aabb, self.min_near)
+            last_begin = ((N - 1) // max_ray_batch) * max_ray_batch          # first ray of the chunk the reference loop ends with
+            ws, dep, img, ag, sigmas, rgbs = fm.render_uniform(o, d, nears, fars, num_steps, last_begin)
+            img = img + (1 - ws).unsqueeze(-1) * (1 if bg_color is None else bg_color)
+            depth.append(dep), image.append(img), agg.append(ag)
+        return {"depth": torch.stack(depth, 0), "image": torch.stack(image, 0), "rgbs": rgbs, "sigmas": sigmas,
+                "aggregated_density": torch.stack(agg, 0)}
+
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         _run = self.run_cuda if self.cuda_ray else self.run
         B, N = rays_o.shape[:2]
         device = rays_o.device
+        if staged and not self.cuda_ray and self.fused and not torch.is_grad_enabled() and self.bg_radius <= 0 \
+                and kwargs.get("upsample_steps", 128) == 0 and not kwargs.get("perturb", False):
+            fm = self.fused_model()
+            if fm is not None and self._aabb_is_cube():
+                return self._render_staged_fused(fm, rays_o, rays_d, max_ray_batch, **kwargs)
         if staged and not self.cuda_ray:
             depth = torch.empty((B, N), device=device)
             image = torch.empty((B, N, 3), device=device)
