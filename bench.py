@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--cpu-stride", type=int, default=16, help="cpu_baseline renders rays[::stride] of view 0")
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the flow)")
     p.add_argument("--no-last", action="store_true", help="do not materialise the last iteration's sigmas/rgbs tensors")
     return p.parse_args()
 
@@ -54,13 +55,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev_index = min(local_rank, torch.cuda.device_count() - 1) if world > 1 else 0   # (a gloo rehearsal may share one GPU)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    dev = torch.device("cuda", dev_index)
     lib = _lib.lib()
     if args.debug_flags:
         lib.ngp_debug_disable_march_queue(args.debug_flags)
@@ -77,12 +82,12 @@ def main():
     def view_of(step):                       # weak scaling: every rank renders its own camera each step
         return (step * world + rank) % n_views
 
-    def render_step(step):
+    def render_step(step, exchange=True):
         v = view_of(step)
         rays = get_rays(poses[v:v + 1], intr, H, W)
         out = model.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False)
         st = model.last_render_stats
-        if world > 1:                        # the path's one exchange step: all-gather the rendered tiles
+        if world > 1 and exchange:           # the path's one exchange step: all-gather the rendered tiles
             gather_views(out["image"], world)
             gather_views(out["depth"], world)
         return st["samples_marched"], st["iterations"], st["samples_slots"]
@@ -113,7 +118,7 @@ def main():
             lib.ngp_prof_enable(1)
             ray_iters = 0
             for i in range(args.profile_steps):
-                render_step(args.warmup + i)
+                render_step(args.warmup + i, exchange=False)   # rank 0 only: no collective in this leg
                 ray_iters += model.last_render_stats["samples_slots"]  # sum over iterations of n_alive * n_step
             torch.cuda.synchronize()
             lib.ngp_prof_enable(0)
@@ -128,7 +133,7 @@ def main():
                         "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
                         "algorithmic_bytes_per_sample": TABLE_BYTES_PER_SAMPLE, "algorithmic_bytes_per_ray_iteration": RAY_BYTES_PER_RAY_ITER}
 
-    tot = torch.tensor([float(samples), float(iters), elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(samples), float(iters), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)

@@ -32,8 +32,15 @@ def gather_views(local, n_total, group=None):
     pad = n_max - local.shape[0]
     if pad > 0:
         local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
-    out = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        # rehearsal mode (CPU collectives): stage through host memory; the production backend is nccl (= RCCL over xGMI)
+        host = local.contiguous().cpu()
+        out_h = host.new_empty((world * n_max,) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out_h, host, group=group)
+        out = out_h.to(local.device)
+    else:
+        out = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     pieces = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
