@@ -142,14 +142,20 @@ NGP_API int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
                         ngp_stream_t stream);
-/* ffmlp.cu:711-895 (fused backward + per-layer weight gradients; no CUTLASS, no side streams).
- * backward_buffer [num_layers,B,hidden]; grad_weights (same shape as weights) is overwritten. */
+/* ffmlp.cu:745-897 ffmlp_backward (+ :410-520 kernel_mlp_fused_backward).  grad [B,16] fp16 is consumed as is (the
+ * reference does not transfer the output activation either, ffmlp.cu:462-464).  backward_buffer [num_layers,B,hidden]:
+ * slot j = dL/d(pre-activation) of forward_buffer[num_layers-1-j]; grad_weights (layout of `weights`) and, when
+ * calc_grad_inputs, grad_inputs [B,input_dim] are overwritten.  Weight gradients are a deterministic split-K over the
+ * batch: fp32 partials in a per-device workspace the library owns (grown on first use, released by
+ * ngp_ffmlp_free_splitk) -- like the reference's split-K state it is shared, so do not run two backward calls
+ * concurrently on different streams of one device.  Everything is enqueued on `stream`. */
 NGP_API int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
                        const uint16_t* forward_buffer, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                        int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
                        uint16_t* grad_weights, ngp_stream_t stream);
-/* ffmlp.cu:721-760: the reference allocates CUTLASS split-K streams here; kept as no-ops. */
+/* ffmlp.cu:721-741: the reference creates CUTLASS split-K streams/events here.  allocate is a no-op (the workspace is
+ * sized by the first backward call); free releases the workspace. */
 NGP_API int ngp_ffmlp_allocate_splitk(size_t n);
 NGP_API int ngp_ffmlp_free_splitk(void);
 

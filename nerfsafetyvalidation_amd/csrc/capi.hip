@@ -131,16 +131,4 @@ int ngp_prof_read(const char* name, double* total_ms, uint64_t* launches, double
     return NGP_EINVAL;
 }
 
-// ffmlp backward: declared in the ABI, implemented in a later round (training path).
-int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer, uint32_t B,
-                       uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
-                       uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
-                       uint16_t* grad_weights, ngp_stream_t stream) {
-    (void)grad; (void)inputs; (void)weights; (void)forward_buffer; (void)B; (void)input_dim; (void)output_dim; (void)hidden_dim;
-    (void)num_layers; (void)activation; (void)output_activation; (void)calc_grad_inputs; (void)backward_buffer; (void)grad_inputs;
-    (void)grad_weights; (void)stream;
-    set_error("ffmlp_backward: not implemented in this build (training path; inference and forward are)");
-    return NGP_EINVAL;
-}
-
 }  // extern "C"

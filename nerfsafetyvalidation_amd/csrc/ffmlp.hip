@@ -19,6 +19,8 @@
 // reference accumulates in fp16 inside WMMA (OUT_T = __half, ffmlp.cu:564).
 #include <hip/hip_fp16.h>
 
+#include <mutex>
+
 #include "ngp_common.hpp"
 
 namespace ngp {
@@ -149,6 +151,348 @@ static int ffmlp_run(const uint16_t* inputs, const uint16_t* weights, uint32_t B
     return check_launch(what);
 }
 
+
+// =====================================================================================
+// Backward (ffmlp.cu:410-520 kernel_mlp_fused_backward, :745-897 ffmlp_backward).
+//
+// Two kernels and a reduction, all on the caller's stream (the reference forks CUTLASS
+// split-K GEMMs onto side streams and joins them with events, ffmlp.cu:795-897):
+//
+//  k_ffmlp_bwd_chain  activation gradients.  Same transposed formulation as the forward:
+//      dH_prev^T = W^T * dH^T, so the accumulators of one layer are the B fragments of the
+//      next and never leave registers.  W^T as the MFMA A operand is W read down its
+//      columns: the matrices are copied row-major into LDS once per workgroup and read
+//      with gfx950's transposing ds_read_b64_tr_b16 -- no transposed copy of the weights.
+//  k_ffmlp_bwd_wgrad  weight gradients dW = G^T * X, a contraction over the batch.  Both
+//      operands are k-strided in memory; a wave streams 16-row slabs of G and X through a
+//      private LDS tile and reads both with ds_read_b64_tr_b16.  The batch is split into
+//      S chunks; every chunk writes fp32 partials to a workspace, k_ffmlp_bwd_reduce sums
+//      them in a fixed order (deterministic, unlike atomics) and rounds to fp16 once.
+//
+// Rounding: fp32 MFMA accumulation, one rounding to fp16 per produced tensor; activation
+// transfer in fp16 arithmetic on the stored post-activations (utils.h:537-580).
+// =====================================================================================
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+__device__ __forceinline__ half4 lds_tr_read(const _Float16* p) {  // EXEC must be all ones
+    const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+    return __builtin_bit_cast(half4, v);
+}
+
+__device__ __forceinline__ _Float16 act_transfer(uint32_t act, _Float16 g, _Float16 f) {  // utils.h:537-580
+    const float K_ACT = 10.0f;
+    switch (act) {
+        case 0: return g * (_Float16)(f > (_Float16)0 ? 1.0f : 0.0f);
+        case 1: return g * f;
+        case 2: return g;  // sine: the reference leaves the gradient untouched (no stored pre-activations)
+        case 3: return g * (f * ((_Float16)1.0f - f));
+        case 4: { const float y = (float)f * K_ACT; return g * (_Float16)(y * y / (y * y + 1.0f)); }
+        case 5: return g * (_Float16)(1.0f - expf(-(float)f * K_ACT));
+        default: return g;
+    }
+}
+
+__device__ __forceinline__ half4 transfer_pack(uint32_t act, const f32x4& acc, half4 f) {
+    half4 h;
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[r] = act_transfer(act, (_Float16)acc[r], f[r]);
+    return h;
+}
+
+__host__ __device__ __forceinline__ uint32_t lds_stride(uint32_t cols) { return cols + (cols == 16 ? 0u : 16u); }
+
+// copy a row-major [rows x cols] fp16 matrix into an LDS image with row stride `stride` (16-byte chunks)
+__device__ __forceinline__ void stage_matrix(_Float16* dst, const _Float16* __restrict__ src, uint32_t rows, uint32_t cols,
+                                             uint32_t stride) {
+    const uint32_t cpr = cols >> 3, n = rows * cpr;
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const uint32_t r = e / cpr, cc = e - r * cpr;
+        *reinterpret_cast<uint4*>(dst + r * stride + cc * 8) = *reinterpret_cast<const uint4*>(src + (size_t)r * cols + cc * 8);
+    }
+}
+
+template <int HB, int TPW>
+__global__ void __launch_bounds__(256) k_ffmlp_bwd_chain(const _Float16* __restrict__ grad, const _Float16* __restrict__ weights,
+                                                         const _Float16* __restrict__ fwd, uint32_t B, uint32_t in_dim, uint32_t L,
+                                                         uint32_t act, _Float16* __restrict__ bwd, _Float16* __restrict__ grad_inputs,
+                                                         uint32_t resident, uint32_t n_groups) {
+    constexpr uint32_t HID = HB * 16;
+    constexpr uint32_t SH = HID + (HID == 16 ? 0 : 16);
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const uint32_t sIn = lds_stride(in_dim), IB = in_dim >> 4;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const uint32_t tr_row = 4 * g + (c >> 2), tr_col = 4 * (c & 3);
+    const uint32_t trl_H = tr_row * SH + tr_col, trl_I = tr_row * sIn + tr_col;
+    const _Float16* W_in = weights;
+    const _Float16* W_hid = weights + (size_t)HID * in_dim;
+    const _Float16* W_out = W_hid + (size_t)(L - 1) * HID * HID;
+    const uint32_t off_hid = 16 * SH, off_in = off_hid + (L - 1) * HID * SH;
+    const size_t BH = (size_t)B * HID;
+    const uint32_t n_tiles = B >> 4;
+    if (resident) {
+        stage_matrix(lds, W_out, 16, HID, SH);
+        for (uint32_t m = 0; m + 1 < L; m++) stage_matrix(lds + off_hid + m * HID * SH, W_hid + (size_t)m * HID * HID, HID, HID, SH);
+        if (grad_inputs) stage_matrix(lds + off_in, W_in, HID, in_dim, sIn);
+        __syncthreads();
+    }
+    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        size_t row[TPW];
+        bool valid[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            const uint32_t tile = (group * 4 + wave) * TPW + t;
+            valid[t] = tile < n_tiles;
+            row[t] = (size_t)(valid[t] ? tile : n_tiles - 1) * 16 + c;
+        }
+        // ---- output matrix: dH_last^T = W_out^T * grad^T, one k block (ffmlp.cu:447-488) ----
+        if (!resident) {
+            __syncthreads();
+            stage_matrix(lds, W_out, 16, HID, SH);
+            __syncthreads();
+        }
+        half4 dh[TPW][HB];
+        {
+            const _Float16* Wl = lds;  // resident image starts with W_out, too
+            half4 gB[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; t++) gB[t] = ld_half4(grad + row[t] * 16 + g * 4);
+            const _Float16* f = fwd + (size_t)(L - 1) * BH;
+#pragma unroll
+            for (int ib = 0; ib < HB; ib++) {
+                const half4 a = lds_tr_read(Wl + trl_H + ib * 16);
+#pragma unroll
+                for (int t = 0; t < TPW; t++) {
+                    const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, gB[t], (f32x4){0, 0, 0, 0}, 0, 0, 0);
+                    dh[t][ib] = transfer_pack(act, acc, ld_half4(f + row[t] * HID + ib * 16 + g * 4));
+                    if (valid[t]) st_half4(bwd + row[t] * HID + ib * 16 + g * 4, dh[t][ib]);
+                }
+            }
+        }
+        // ---- hidden matrices, last to first (ffmlp.cu:507-509) ----
+        for (uint32_t k = 0; k + 1 < L; k++) {
+            const uint32_t m = L - 2 - k;
+            if (!resident) {
+                __syncthreads();
+                stage_matrix(lds, W_hid + (size_t)m * HID * HID, HID, HID, SH);
+                __syncthreads();
+            }
+            const _Float16* Wl = lds + (resident ? off_hid + m * HID * SH : 0);
+            const _Float16* f = fwd + (size_t)m * BH;
+            _Float16* o = bwd + (size_t)(k + 1) * BH;
+            half4 dn[TPW][HB];
+#pragma unroll
+            for (int ib = 0; ib < HB; ib++) {
+                f32x4 acc[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; t++) acc[t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) {
+                    const half4 a = lds_tr_read(Wl + trl_H + ob * 16 * SH + ib * 16);
+#pragma unroll
+                    for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, dh[t][ob], acc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; t++) {
+                    dn[t][ib] = transfer_pack(act, acc[t], ld_half4(f + row[t] * HID + ib * 16 + g * 4));
+                    if (valid[t]) st_half4(o + row[t] * HID + ib * 16 + g * 4, dn[t][ib]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; t++)
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++) dh[t][ib] = dn[t][ib];
+        }
+        // ---- dL/dinput = dH_0 * W_in (ffmlp.cu:515-517 when widths match, :880-887 otherwise) ----
+        if (grad_inputs) {
+            if (!resident) {
+                __syncthreads();
+                stage_matrix(lds, W_in, HID, in_dim, sIn);
+                __syncthreads();
+            }
+            const _Float16* Wl = lds + (resident ? off_in : 0);
+            for (uint32_t ib = 0; ib < IB; ib++) {
+                f32x4 acc[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; t++) acc[t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) {
+                    const half4 a = lds_tr_read(Wl + trl_I + ob * 16 * sIn + ib * 16);
+#pragma unroll
+                    for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, dh[t][ob], acc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; t++) {
+                    half4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h[r] = (_Float16)acc[t][r];
+                    if (valid[t]) st_half4(grad_inputs + row[t] * in_dim + ib * 16 + g * 4, h);
+                }
+            }
+        }
+    }
+}
+
+// One wave per workgroup.  blockIdx.x = batch chunk, blockIdx.y = unit: up to 4x4 output fragments of one matrix.
+__global__ void __launch_bounds__(64) k_ffmlp_bwd_wgrad(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
+                                                        const _Float16* __restrict__ fwd, const _Float16* __restrict__ bwd, uint32_t B,
+                                                        uint32_t in_dim, uint32_t HID, uint32_t L, uint32_t chunk_rows,
+                                                        float* __restrict__ ws, uint32_t P) {
+    constexpr uint32_t TS = 80;  // LDS row stride in halves: 64 columns + 32 bytes, conflict-free for the transposing read
+    __shared__ __attribute__((aligned(16))) _Float16 tileG[16 * TS];
+    __shared__ __attribute__((aligned(16))) _Float16 tileX[16 * TS];
+    const uint32_t lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const uint32_t HB = HID >> 4, IBin = in_dim >> 4, HG = (HB + 3) >> 2, IG = (IBin + 3) >> 2;
+    const size_t BH = (size_t)B * HID;
+    // ---- decode the unit (all wave-uniform) ----
+    uint32_t u = blockIdx.y;
+    const _Float16 *G, *X;
+    uint32_t rows, cols, og, ig, w_off;
+    const uint32_t n_in = HG * IG, n_hid = HG * HG;
+    if (u < n_in) {  // input matrix: dW_in = bwd[L-1]^T * inputs
+        G = bwd + (size_t)(L - 1) * BH; rows = HID; X = inputs; cols = in_dim; og = u / IG; ig = u - og * IG; w_off = 0;
+    } else if ((u -= n_in) < (L - 1) * n_hid) {  // hidden matrix m: bwd[L-2-m]^T * fwd[m]
+        const uint32_t m = u / n_hid, r = u - m * n_hid;
+        G = bwd + (size_t)(L - 2 - m) * BH; rows = HID; X = fwd + (size_t)m * BH; cols = HID; og = r / HG; ig = r - og * HG;
+        w_off = HID * in_dim + m * HID * HID;
+    } else {  // output matrix: grad^T * fwd[L-1]
+        u -= (L - 1) * n_hid;
+        G = grad; rows = 16; X = fwd + (size_t)(L - 1) * BH; cols = HID; og = 0; ig = u;
+        w_off = HID * in_dim + (L - 1) * HID * HID;
+    }
+    const uint32_t nob = min(4u, (rows >> 4) - og * 4), nib = min(4u, (cols >> 4) - ig * 4);
+    const uint32_t b0 = blockIdx.x * chunk_rows, b1 = min(B, b0 + chunk_rows);
+    const uint32_t n_steps = b1 > b0 ? (b1 - b0) >> 4 : 0;
+    // staging map: lane moves 8-byte chunk (row = g + 4j, chunk column = c) of the 16 x 64 slab
+    const bool g_on = c < nob * 4, x_on = c < nib * 4;
+    const _Float16* gp = G + (size_t)(b0 + g) * rows + og * 64 + c * 4;
+    const _Float16* xp = X + (size_t)(b0 + g) * cols + ig * 64 + c * 4;
+    const uint32_t tr_off = (4 * g + (c >> 2)) * TS + 4 * (c & 3);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[o][i] = (f32x4){0, 0, 0, 0};
+    half4 gr[4], xr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { gr[j] = (half4){0, 0, 0, 0}; xr[j] = (half4){0, 0, 0, 0}; }
+    if (n_steps) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (g_on) gr[j] = ld_half4(gp + (size_t)(4 * j) * rows);
+            if (x_on) xr[j] = ld_half4(xp + (size_t)(4 * j) * cols);
+        }
+    }
+    for (uint32_t ks = 0; ks < n_steps; ks++) {
+        __syncthreads();  // the previous step's transposed reads are done
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            st_half4(tileG + (g + 4 * j) * TS + c * 4, gr[j]);
+            st_half4(tileX + (g + 4 * j) * TS + c * 4, xr[j]);
+        }
+        if (ks + 1 < n_steps) {  // next slab in flight while this one is multiplied
+            gp += (size_t)16 * rows;
+            xp += (size_t)16 * cols;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (g_on) gr[j] = ld_half4(gp + (size_t)(4 * j) * rows);
+                if (x_on) xr[j] = ld_half4(xp + (size_t)(4 * j) * cols);
+            }
+        }
+        __syncthreads();
+        half4 a[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) a[o] = lds_tr_read(tileG + tr_off + o * 16);  // columns >= nob*16 hold zeros
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < (int)nib) {
+                const half4 b = lds_tr_read(tileX + tr_off + i * 16);
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    if (o < (int)nob) acc[o][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[o], b, acc[o][i], 0, 0, 0);
+            }
+        }
+    }
+    float* out = ws + (size_t)blockIdx.x * P + w_off;
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (o < (int)nob && i < (int)nib) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    out[(size_t)(og * 64 + o * 16 + 4 * g + r) * cols + ig * 64 + i * 16 + c] = acc[o][i][r];
+            }
+}
+
+// fixed-order sum of the S partials of every parameter, one rounding to fp16
+__global__ void __launch_bounds__(256) k_ffmlp_bwd_reduce(const float* __restrict__ ws, uint32_t S, uint32_t P,
+                                                          _Float16* __restrict__ grad_weights) {
+    __shared__ float part[4][64];
+    const uint32_t p = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float s = 0;
+    if (p < P)
+        for (uint32_t k = q; k < S; k += 4) s += ws[(size_t)k * P + p];
+    part[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && p < P) grad_weights[p] = (_Float16)(((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
+}
+
+// fp32 split-K workspace, one per device, grown on demand (the reference's counterpart is the CUTLASS
+// workspace behind allocate_splitk/free_splitk, ffmlp.cu:711-741)
+static std::mutex g_ws_mu;
+static float* g_ws[32] = {};
+static size_t g_ws_bytes[32] = {};
+
+static float* splitk_workspace(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (g_ws_bytes[dev] < bytes) {
+        if (g_ws[dev]) (void)hipFree(g_ws[dev]);  // hipFree waits for work that still uses it
+        g_ws[dev] = nullptr;
+        g_ws_bytes[dev] = 0;
+        if (hipMalloc((void**)&g_ws[dev], bytes) != hipSuccess) return nullptr;
+        g_ws_bytes[dev] = bytes;
+    }
+    return g_ws[dev];
+}
+
+static void splitk_release() {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < 32; d++)
+        if (g_ws[d]) {
+            (void)hipSetDevice(d);
+            (void)hipFree(g_ws[d]);
+            g_ws[d] = nullptr;
+            g_ws_bytes[d] = 0;
+        }
+    (void)hipSetDevice(cur);
+}
+
+template <int HB, int TPW>
+static void launch_bwd_chain(const uint16_t* grad, const uint16_t* w, const uint16_t* fwd, uint32_t B, uint32_t in_dim, uint32_t L,
+                             uint32_t act, uint16_t* bwd, uint16_t* gi, hipStream_t s) {
+    constexpr uint32_t HID = HB * 16;
+    const uint32_t SH = lds_stride(HID), sIn = lds_stride(in_dim);
+    const size_t all = ((size_t)16 * SH + (size_t)(L - 1) * HID * SH + (gi ? (size_t)HID * sIn : 0)) * 2;
+    const size_t one = (size_t)HID * (SH > sIn || !gi ? SH : sIn) * 2;
+    const uint32_t resident = all <= 64 * 1024 ? 1 : 0;  // 2 workgroups per CU keep their weights; larger nets stream per layer
+    const size_t lds = resident ? all : one;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffmlp_bwd_chain<HB, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    const uint32_t n_tiles = B / 16, n_groups = div_up(n_tiles, 4 * TPW);
+    const uint32_t per_cu = lds <= 32 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
+    uint32_t blocks = n_groups < 256 * per_cu ? n_groups : 256 * per_cu;
+    k_ffmlp_bwd_chain<HB, TPW><<<blocks, 256, lds, s>>>((const _Float16*)grad, (const _Float16*)w, (const _Float16*)fwd, B, in_dim, L, act,
+                                                        (_Float16*)bwd, (_Float16*)gi, resident, n_groups);
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -171,7 +515,55 @@ int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
                      (hipStream_t)stream, "ffmlp_inference");
 }
 
+int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer, uint32_t B,
+                       uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                       uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
+                       uint16_t* grad_weights, ngp_stream_t stream) {
+    (void)output_activation;  // not transferred by the reference either (ffmlp.cu:462-464); FFMLP always passes `none`
+    if (B == 0) return NGP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights, "ffmlp_backward: null pointer");
+    NGP_REQUIRE(!calc_grad_inputs || grad_inputs, "ffmlp_backward: calc_grad_inputs without a grad_inputs buffer");
+    NGP_REQUIRE(B % 16 == 0, "ffmlp_backward: batch size must be a multiple of 16 (got %u)", B);
+    NGP_REQUIRE(input_dim > 0 && input_dim % 16 == 0, "FFMLP input_dim should be 16 * m (m > 0), but got %u", input_dim);
+    NGP_REQUIRE(output_dim == 16, "FFMLP current only supports (padded) output dim == 16, but got %u", output_dim);
+    NGP_REQUIRE(num_layers >= 2, "FFMLP num_layers should be larger than 2 (3 matmuls), but got %u", num_layers);
+    NGP_REQUIRE(hidden_dim == 16 || hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128 || hidden_dim == 256,
+                "FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got %u", hidden_dim);
+    uint16_t* gi = calc_grad_inputs ? grad_inputs : nullptr;
+    const uint32_t P = hidden_dim * (input_dim + (num_layers - 1) * hidden_dim + 16);
+    // batch split of the weight-gradient contraction: ~256 rows per chunk, at most 1024 chunks / 256 MB of partials
+    uint32_t S = B / 256 ? B / 256 : 1;
+    if (S > 1024) S = 1024;
+    const size_t cap = ((size_t)256 << 20) / ((size_t)P * 4);
+    if (S > cap) S = cap ? (uint32_t)cap : 1;
+    const uint32_t chunk = div_up(div_up(B, S), 16) * 16;
+    S = div_up(B, chunk);
+    float* ws = splitk_workspace((size_t)S * P * 4);
+    NGP_REQUIRE(ws, "ffmlp_backward: cannot allocate %zu bytes of split-K workspace", (size_t)S * P * 4);
+    ProfScope prof("ffmlp_backward", s, B);
+    switch (hidden_dim) {
+        case 16: launch_bwd_chain<1, 4>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
+        case 32: launch_bwd_chain<2, 4>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
+        case 64: launch_bwd_chain<4, 4>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
+        case 128: launch_bwd_chain<8, 2>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
+        default: launch_bwd_chain<16, 1>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
+    }
+    int rc = check_launch("ffmlp_backward (activation gradients)");
+    if (rc) return rc;
+    const uint32_t HG = div_up(hidden_dim / 16, 4), IG = div_up(input_dim / 16, 4);
+    const uint32_t units = HG * IG + (num_layers - 1) * HG * HG + HG;
+    k_ffmlp_bwd_wgrad<<<dim3(S, units), 64, 0, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)forward_buffer,
+                                                    (const _Float16*)backward_buffer, B, input_dim, hidden_dim, num_layers, chunk, ws, P);
+    rc = check_launch("ffmlp_backward (weight gradients)");
+    if (rc) return rc;
+    k_ffmlp_bwd_reduce<<<div_up(P, 64), 256, 0, s>>>(ws, S, P, (_Float16*)grad_weights);
+    return check_launch("ffmlp_backward (split-K reduction)");
+}
+
+// The reference creates its split-K side streams here (ffmlp.cu:721-741); this library's split-K workspace is
+// allocated on first use, so allocate is a no-op and free releases the workspace.
 int ngp_ffmlp_allocate_splitk(size_t n) { (void)n; return NGP_OK; }
-int ngp_ffmlp_free_splitk(void) { return NGP_OK; }
+int ngp_ffmlp_free_splitk(void) { splitk_release(); return NGP_OK; }
 
 }  // extern "C"

@@ -803,6 +803,93 @@ ORACLE_API void oracle_ffmlp_forward(const uint16_t* inputs, const uint16_t* wei
     }
 }
 
+/* ffmlp/src/ffmlp.cu:410-520 kernel_mlp_fused_backward + :745-897 ffmlp_backward + utils.h:537-580.
+ * backward_buffer[j] ([B, hidden], j = 0..num_layers-1) holds dL/d(pre-activation) of hidden state
+ * forward_buffer[num_layers-1-j]: j = 0 is the last hidden state (fed by the output matrix).
+ * The output activation is NOT transferred (ffmlp.cu:462-464: "expected to be done prior"; FFMLP always
+ * uses none), so `grad` is consumed as is.  Activation transfer uses the stored POST-activation values
+ * with __half arithmetic (product of two halves rounded to half).  Matmuls: exact products summed in
+ * double, rounded to fp32 then fp16 (the CUDA reference accumulates in fp16 inside WMMA for the
+ * activation chain and in CUTLASS split-K for the weight gradients -- not reproducible elsewhere;
+ * tolerance in tests/test_ops_gpu.py). */
+static inline half_t hmul(half_t a, half_t b) { return f2h(h2f(a) * h2f(b)); }
+
+static inline half_t act_transfer(uint32_t act, half_t g, half_t fwd) { /* utils.h:537-580 */
+    const float K_ACT = 10.0f;
+    switch (act) {
+        case 0: return h2f(fwd) > 0.0f ? g : f2h(h2f(g) * 0.0f);       /* g * (T)(fwd > 0) keeps the sign of zero */
+        case 1: return hmul(g, fwd);
+        case 2: return g;                                              /* sine: no stored pre-activations, left as is */
+        case 3: { half_t om = f2h(1.0f - h2f(fwd)); return hmul(g, hmul(fwd, om)); }
+        case 4: { float y = h2f(fwd) * K_ACT; return hmul(g, f2h(y * y / (y * y + 1.0f))); }
+        case 5: return hmul(g, f2h(1.0f - expf(-h2f(fwd) * K_ACT)));
+        default: return g;
+    }
+}
+
+ORACLE_API void oracle_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
+                                      const uint16_t* forward_buffer, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, int calc_grad_inputs,
+                                      uint16_t* backward_buffer, uint16_t* grad_inputs, uint16_t* grad_weights) {
+    const size_t HH = (size_t)hidden_dim * hidden_dim, BH = (size_t)B * hidden_dim;
+    const half_t* W_in = weights;
+    const half_t* W_hid = weights + (size_t)hidden_dim * input_dim;
+    const half_t* W_out = W_hid + (size_t)(num_layers - 1) * HH;
+    /* ---- activation-gradient chain, one batch row at a time ---- */
+    #pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        half_t cur[256], nxt[256];
+        const half_t* g = grad + (size_t)b * output_dim;
+        const half_t* f = forward_buffer + (size_t)(num_layers - 1) * BH + (size_t)b * hidden_dim;
+        for (uint32_t i = 0; i < hidden_dim; i++) {
+            double acc = 0;
+            for (uint32_t o = 0; o < output_dim; o++) acc += (double)h2f(g[o]) * (double)h2f(W_out[(size_t)o * hidden_dim + i]);
+            cur[i] = act_transfer(activation, f2h((float)acc), f[i]);
+        }
+        memcpy(backward_buffer + (size_t)b * hidden_dim, cur, hidden_dim * 2);
+        for (uint32_t k = 0; k + 1 < num_layers; k++) {
+            const uint32_t m = num_layers - 2 - k;                     /* hidden matrix m maps forward[m] -> forward[m+1] */
+            const half_t* W = W_hid + (size_t)m * HH;
+            f = forward_buffer + (size_t)m * BH + (size_t)b * hidden_dim;
+            for (uint32_t i = 0; i < hidden_dim; i++) {
+                double acc = 0;
+                for (uint32_t o = 0; o < hidden_dim; o++) acc += (double)h2f(cur[o]) * (double)h2f(W[(size_t)o * hidden_dim + i]);
+                nxt[i] = act_transfer(activation, f2h((float)acc), f[i]);
+            }
+            memcpy(cur, nxt, hidden_dim * 2);
+            memcpy(backward_buffer + (size_t)(k + 1) * BH + (size_t)b * hidden_dim, cur, hidden_dim * 2);
+        }
+        if (calc_grad_inputs && grad_inputs) {                          /* ffmlp.cu:515-517 (fused) == :880-887 (fc_multiply) */
+            for (uint32_t i = 0; i < input_dim; i++) {
+                double acc = 0;
+                for (uint32_t o = 0; o < hidden_dim; o++) acc += (double)h2f(cur[o]) * (double)h2f(W_in[(size_t)o * input_dim + i]);
+                grad_inputs[(size_t)b * input_dim + i] = f2h((float)acc);
+            }
+        }
+    }
+    /* ---- weight gradients: dW[o][i] = sum_b G[b][o] * X[b][i]  (ffmlp.cu:795-876) ---- */
+    for (uint32_t mat = 0; mat <= num_layers; mat++) {
+        const half_t *G, *X; uint32_t rows, cols; half_t* dW;
+        if (mat == 0) {            /* input matrix */
+            G = backward_buffer + (size_t)(num_layers - 1) * BH; rows = hidden_dim; X = inputs; cols = input_dim; dW = grad_weights;
+        } else if (mat < num_layers) { /* hidden matrix m = mat-1 */
+            const uint32_t m = mat - 1;
+            G = backward_buffer + (size_t)(num_layers - 2 - m) * BH; rows = hidden_dim;
+            X = forward_buffer + (size_t)m * BH; cols = hidden_dim; dW = grad_weights + (size_t)hidden_dim * input_dim + (size_t)m * HH;
+        } else {                   /* output matrix */
+            G = grad; rows = output_dim; X = forward_buffer + (size_t)(num_layers - 1) * BH; cols = hidden_dim;
+            dW = grad_weights + (size_t)hidden_dim * input_dim + (size_t)(num_layers - 1) * HH;
+        }
+        #pragma omp parallel for schedule(static)
+        for (int64_t oi = 0; oi < (int64_t)rows * cols; oi++) {
+            const uint32_t o = (uint32_t)(oi / cols), i = (uint32_t)(oi % cols);
+            double acc = 0;
+            for (uint32_t b = 0; b < B; b++) acc += (double)h2f(G[(size_t)b * rows + o]) * (double)h2f(X[(size_t)b * cols + i]);
+            dW[oi] = f2h((float)acc);
+        }
+    }
+}
+
 /* Generic dense MLP in fp32 (the nerf/network.py backbone: nn.Linear, bias=False,
  * ReLU between layers; nerf/network.py:100-106,112-119).  dims[0..n] are layer widths;
  * weights are concatenated W_k[dims[k+1]][dims[k]] row-major (nn.Linear.weight). */

@@ -189,6 +189,13 @@ def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_l
                   None, outputs)
 
 
+def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                   output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights):
+    lib().oracle_ffmlp_backward(_p(grad), _p(inputs), _p(weights), _p(forward_buffer), u32(B), u32(input_dim), u32(output_dim),
+                                u32(hidden_dim), u32(num_layers), u32(activation), C.c_int(int(calc_grad_inputs)),
+                                _p(backward_buffer), _p(grad_inputs), _p(grad_weights))
+
+
 def allocate_splitk(n):
     pass
 

@@ -283,6 +283,90 @@ def test_ffmlp_inference_and_forward(device, hidden, in_dim, num_layers, B):
     assert (got == want.astype(np.float32)).mean() > 0.5
 
 
+@pytest.mark.parametrize("hidden,in_dim,num_layers,B,act", [(64, 32, 2, 1000, "relu"), (64, 64, 3, 4096, "relu"), (16, 16, 2, 77, "relu"),
+                                                            (32, 48, 4, 300, "relu"), (128, 32, 2, 700, "relu"), (256, 64, 3, 260, "relu"),
+                                                            (64, 32, 2, 200, "sigmoid"), (32, 32, 3, 130, "squareplus"),
+                                                            (64, 32, 2, 9000, "relu")])
+def test_ffmlp_backward(device, hidden, in_dim, num_layers, B, act):
+    """ngp_ffmlp_backward through the FFMLP module vs the oracle restatement of ffmlp.cu:410-520/:745-897."""
+    from nerfsafetyvalidation_amd.ffmlp import FFMLP
+    from nerfsafetyvalidation_amd.ffmlp.ffmlp import convert_activation
+    rng = np.random.default_rng(17)
+    net = FFMLP(in_dim, 13, hidden, num_layers, activation=act).to(device).train()
+    if act != "relu":
+        net.weights.data.mul_(0.5)
+    x = rng.uniform(-1, 1, (B, in_dim)).astype(np.float16)
+    g = rng.uniform(-1, 1, (B, 13)).astype(np.float16)
+    xt = torch.from_numpy(x).to(device).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = net(xt)
+    y.backward(torch.from_numpy(g).to(device))
+    got_gw = net.weights.grad.detach().float().cpu().numpy()
+    got_gi = xt.grad.detach().float().cpu().numpy()
+    # oracle on the padded problem the wrapper builds (F11: 1..128 zero rows, outputs padded to 16)
+    Bp = B + 128 - B % 128
+    a = convert_activation(act)
+    w16 = net.weights.detach().cpu().half().numpy()
+    xp = np.zeros((Bp, in_dim), np.float16); xp[:B] = x
+    gp = np.zeros((Bp, 16), np.float16); gp[:B, :13] = g
+    fwd = np.zeros((num_layers, Bp, hidden), np.float16)
+    out = np.zeros((Bp, 16), np.float16)
+    O.ffmlp_forward(xp, w16, Bp, in_dim, 16, hidden, num_layers, a, 6, fwd, out)
+    bwd = np.zeros((num_layers, Bp, hidden), np.float16)
+    gi = np.zeros((Bp, in_dim), np.float16)
+    gw = np.zeros(w16.size, np.float16)
+    O.ffmlp_backward(gp, xp, w16, fwd, Bp, in_dim, 16, hidden, num_layers, a, 6, True, bwd, gi, gw)
+    want_gw, want_gi = gw.astype(np.float32), gi[:B].astype(np.float32)
+    assert got_gw.shape == want_gw.shape and got_gi.shape == want_gi.shape
+    # fp32 MFMA sums vs exact sums, each rounded to fp16: hidden gradients differ by <= 1 fp16 ulp where a sum falls near a
+    # rounding boundary, and the forward activations the two sides start from differ the same way (see the forward test)
+    scale_w = np.abs(want_gw).max()
+    np.testing.assert_allclose(got_gi, want_gi, rtol=8e-3, atol=8e-3 * max(1.0, np.abs(want_gi).max()))
+    np.testing.assert_allclose(got_gw, want_gw, rtol=8e-3, atol=4e-3 * scale_w)
+    assert (got_gw == want_gw).mean() > 0.4 and (got_gi == want_gi).mean() > 0.4
+
+
+def test_ffmlp_backward_buffers_direct(device):
+    """The raw entry point with oracle-produced forward activations: every output tensor, incl. backward_buffer."""
+    from nerfsafetyvalidation_amd import _lib
+    rng = np.random.default_rng(23)
+    B, nin, hid, nl = 2048 + 16, 32, 64, 3
+    P = hid * (nin + hid * (nl - 1) + 16)
+    w = rng.uniform(-0.25, 0.25, P).astype(np.float16)
+    x = rng.uniform(-1, 1, (B, nin)).astype(np.float16)
+    g = rng.uniform(-1, 1, (B, 16)).astype(np.float16)
+    fwd = np.zeros((nl, B, hid), np.float16)
+    out = np.zeros((B, 16), np.float16)
+    O.ffmlp_forward(x, w, B, nin, 16, hid, nl, 0, 6, fwd, out)
+    want = [np.zeros((nl, B, hid), np.float16), np.zeros((B, nin), np.float16), np.zeros(P, np.float16)]
+    O.ffmlp_backward(g, x, w, fwd, B, nin, 16, hid, nl, 0, 6, True, *want)
+    dev = [torch.from_numpy(a).to(device) for a in (g, x, w, fwd)]
+    got = [torch.full((nl, B, hid), 7.0, dtype=torch.float16, device=device), torch.full((B, nin), 7.0, dtype=torch.float16, device=device),
+           torch.full((P,), 7.0, dtype=torch.float16, device=device)]
+    lib = _lib.lib()
+    for calc in (1, 0):
+        _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6,
+                                          calc, _lib.ptr(got[0]), _lib.ptr(got[1]) if calc else None, _lib.ptr(got[2]), _lib.stream()),
+                   "ffmlp_backward")
+        torch.cuda.synchronize()
+        gb, gi, gw = [t.float().cpu().numpy() for t in got]
+        wb, wi, ww = [a.astype(np.float32) for a in want]
+        # same fp16 inputs on both sides: only fp32-vs-exact accumulation separates them
+        np.testing.assert_allclose(gb, wb, rtol=4e-3, atol=2e-3)
+        assert (gb == wb).mean() > 0.98
+        np.testing.assert_allclose(gi, wi, rtol=4e-3, atol=2e-3)
+        np.testing.assert_allclose(gw, ww, rtol=4e-3, atol=2e-3 * np.abs(ww).max())
+        assert (gw == ww).mean() > 0.9
+    # determinism of the split-K reduction: two calls, identical bits
+    first = got[2].clone()
+    _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6, 0,
+                                      _lib.ptr(got[0]), None, _lib.ptr(got[2]), _lib.stream()), "ffmlp_backward")
+    assert torch.equal(first, got[2])
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, 48, nl, 0, 6, 0,
+                                          _lib.ptr(got[0]), None, _lib.ptr(got[2]), _lib.stream()), "ffmlp_backward")
+
+
 def test_ffmlp_rejects_bad_shapes(device):
     from nerfsafetyvalidation_amd.ffmlp import FFMLP
     with pytest.raises(AssertionError):

@@ -209,3 +209,56 @@ def test_ffmlp_oracle_is_a_plain_relu_mlp():
     h = np.maximum(h @ W2.T, 0).astype(np.float32).astype(np.float16).astype(np.float64)
     want = (h @ W3.T).astype(np.float32).astype(np.float16).astype(np.float32)
     assert np.array_equal(got, want)                            # n+1 matmuls, fp16 rounding after every layer
+
+
+def test_ffmlp_backward_oracle_matches_numpy_chain_rule():
+    """oracle_ffmlp_backward == the chain rule in float64 with one fp16 rounding per produced tensor
+    (ffmlp.cu:410-520 for the activation chain, :795-887 for the weight / input gradients)."""
+    rng = np.random.default_rng(9)
+    B, nin, hid, nl = 48, 32, 32, 3
+    P = hid * (nin + hid * (nl - 1) + 16)
+    w = rng.uniform(-0.3, 0.3, P).astype(np.float16)
+    x = rng.uniform(-1, 1, (B, nin)).astype(np.float16)
+    g = rng.uniform(-1, 1, (B, 16)).astype(np.float16)
+    fwd = np.zeros((nl, B, hid), np.float16)
+    out = np.zeros((B, 16), np.float16)
+    O.ffmlp_forward(x, w, B, nin, 16, hid, nl, 0, 6, fwd, out)
+    bwd = np.zeros((nl, B, hid), np.float16)
+    gi = np.zeros((B, nin), np.float16)
+    gw = np.zeros(P, np.float16)
+    O.ffmlp_backward(g, x, w, fwd, B, nin, 16, hid, nl, 0, 6, True, bwd, gi, gw)
+
+    def r16(a):
+        return a.astype(np.float32).astype(np.float16)
+
+    f64 = np.float64
+    W_in = w[:hid * nin].reshape(hid, nin).astype(f64)
+    W_h = [w[hid * nin + m * hid * hid: hid * nin + (m + 1) * hid * hid].reshape(hid, hid).astype(f64) for m in range(nl - 1)]
+    W_out = w[hid * nin + (nl - 1) * hid * hid:].reshape(16, hid).astype(f64)
+    d = r16(g.astype(f64) @ W_out) * (fwd[nl - 1] > 0)
+    want_bwd = [d]
+    for k in range(nl - 1):
+        m = nl - 2 - k
+        d = r16(d.astype(f64) @ W_h[m]) * (fwd[m] > 0)
+        want_bwd.append(d)
+    assert np.array_equal(bwd.astype(np.float32), np.stack(want_bwd).astype(np.float32))
+    assert np.array_equal(gi, r16(want_bwd[-1].astype(f64) @ W_in))
+    want_w = [r16(want_bwd[-1].astype(f64).T @ x.astype(f64)).ravel()]
+    for m in range(nl - 1):
+        want_w.append(r16(want_bwd[nl - 2 - m].astype(f64).T @ fwd[m].astype(f64)).ravel())
+    want_w.append(r16(g.astype(f64).T @ fwd[nl - 1].astype(f64)).ravel())
+    assert np.array_equal(gw, np.concatenate(want_w))
+    # and it is the gradient of the forward: compare with torch autograd on the same network in float64
+    import torch
+    tw = torch.tensor(w.astype(f64), requires_grad=True)
+    tx = torch.tensor(x.astype(f64), requires_grad=True)
+    h = torch.relu(tx @ tw[:hid * nin].view(hid, nin).T)
+    off = hid * nin
+    for m in range(nl - 1):
+        h = torch.relu(h @ tw[off:off + hid * hid].view(hid, hid).T)
+        off += hid * hid
+    y = h @ tw[off:].view(16, hid).T
+    y.backward(torch.tensor(g.astype(f64)))
+    # the float64 network has un-rounded hidden states: agreement to fp16 accuracy of O(1)-sized sums
+    np.testing.assert_allclose(gw.astype(f64), tw.grad.numpy(), rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(gi.astype(f64), tx.grad.numpy(), rtol=2e-2, atol=1e-2)
