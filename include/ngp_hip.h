@@ -167,6 +167,12 @@ NGP_API int ngp_ffmlp_free_splitk(void);
  * n_pix is H*W when pixel_inds is NULL. */
 NGP_API int ngp_get_rays(const float* poses, uint32_t Bc, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
                  const int32_t* pixel_inds, uint32_t n_pix, float* rays_o, float* rays_d, ngp_stream_t stream);
+/* Vector-Jacobian product of the above with respect to the poses (what torch autograd gives for the reference's torch
+ * ops, nerf/utils.py:103-111): grad_rays_o / grad_rays_d [Bc,n_pix,3] f32 (either may be NULL = zero) ->
+ * grad_poses [Bc,4,4] f32, overwritten (row 3 is zero).  Deterministic. */
+NGP_API int ngp_get_rays_backward(const float* grad_rays_o, const float* grad_rays_d, uint32_t Bc, float fx, float fy, float cx, float cy,
+                          uint32_t H, uint32_t W, const int32_t* pixel_inds, uint32_t n_pix, float* grad_poses,
+                          ngp_stream_t stream);
 
 /* ---------------- fused render path behind NeRFRenderer.run_cuda (renderer.py:329-378) ---------------- */
 

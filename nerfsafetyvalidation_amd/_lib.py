@@ -66,6 +66,7 @@ SIGNATURES = {
     "ngp_ffmlp_allocate_splitk": [_sz],
     "ngp_ffmlp_free_splitk": [],
     "ngp_get_rays": [_vp, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _u32, _vp, _vp, _vp],
+    "ngp_get_rays_backward": [_vp, _vp, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _u32, _vp, _vp],
     "ngp_render_ctx_create": [_u32, C.POINTER(_vp)],
     "ngp_render_ctx_destroy": [_vp],
     "ngp_render_rays": [_vp, C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,

@@ -413,6 +413,50 @@ __global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ p
     rays_o[o + 2] = P[11];
 }
 
+// d/dpose of get_rays: rays_o = pose[:3,3] and rays_d = R @ dir are linear in the pose, so
+//   grad_pose[k][3] = sum_p grad_rays_o[p][k],   grad_pose[k][m] = sum_p grad_rays_d[p][k] * dir[p][m]
+// (what torch autograd derives for nerf/utils.py:103-111; the Estimator differentiates rendered pixels with respect to
+// the pose through it, nav/estimator_helpers.py:191-225).  One 1024-thread workgroup per camera, fixed-order tree
+// reduction: deterministic.
+__global__ void __launch_bounds__(1024) k_get_rays_backward(const float* __restrict__ grad_rays_o, const float* __restrict__ grad_rays_d,
+                                                            float fx, float fy, float cx, float cy, uint32_t W,
+                                                            const int32_t* __restrict__ pixel_inds, uint32_t n_pix,
+                                                            float* __restrict__ grad_poses) {
+    __shared__ float red[12][1024 / 64];
+    const uint32_t cam = blockIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] = 0.0f;
+    for (uint32_t p = threadIdx.x; p < n_pix; p += 1024) {
+        const uint32_t pix = pixel_inds ? (uint32_t)pixel_inds[p] : p;
+        const float i = (float)(pix % W) + 0.5f, j = (float)(pix / W) + 0.5f;
+        const float xs = (i - cx) / fx, ys = (j - cy) / fy, zs = 1.0f;
+        const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
+        const float u[3] = {xs / nrm, ys / nrm, zs / nrm};
+        const size_t o = ((size_t)cam * n_pix + p) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float gd = grad_rays_d ? grad_rays_d[o + k] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < 3; m++) acc[k * 4 + m] += gd * u[m];
+            acc[k * 4 + 3] += grad_rays_o ? grad_rays_o[o + k] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        float v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float v = 0.0f;
+        if (threadIdx.x < 12)
+            for (int w = 0; w < 1024 / 64; w++) v += red[threadIdx.x][w];
+        grad_poses[(size_t)cam * 16 + threadIdx.x] = v;  // row 3 of the 4x4 pose does not enter get_rays
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -550,6 +594,15 @@ int ngp_get_rays(const float* poses, uint32_t Bc, float fx, float fy, float cx, 
     dim3 grid(div_up(n_pix, kBlock), Bc);
     k_get_rays<<<grid, kBlock, 0, (hipStream_t)stream>>>(poses, Bc, fx, fy, cx, cy, H, W, pixel_inds, n_pix, rays_o, rays_d);
     return check_launch("get_rays");
+}
+
+int ngp_get_rays_backward(const float* grad_rays_o, const float* grad_rays_d, uint32_t Bc, float fx, float fy, float cx, float cy, uint32_t H,
+                          uint32_t W, const int32_t* pixel_inds, uint32_t n_pix, float* grad_poses, ngp_stream_t stream) {
+    if (Bc == 0) return NGP_OK;
+    NGP_REQUIRE(grad_poses, "get_rays_backward: null pointer");
+    NGP_REQUIRE(pixel_inds || n_pix == H * W, "get_rays_backward: n_pix must be H*W when pixel_inds is NULL");
+    k_get_rays_backward<<<Bc, 1024, 0, (hipStream_t)stream>>>(grad_rays_o, grad_rays_d, fx, fy, cx, cy, W, pixel_inds, n_pix, grad_poses);
+    return check_launch("get_rays_backward");
 }
 
 }  // extern "C"

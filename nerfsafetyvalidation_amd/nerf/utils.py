@@ -17,18 +17,40 @@ def custom_meshgrid(*args):
     return torch.meshgrid(*args, indexing="ij")
 
 
+class _RaysKernel(torch.autograd.Function):
+    """ngp_get_rays with its vector-Jacobian product: the reference builds rays with differentiable torch ops
+    (utils.py:103-111) and the Estimator / Planner differentiate through them with respect to the pose."""
+
+    @staticmethod
+    def forward(ctx, poses, intrinsics, H, W, inds):
+        poses = poses.float().contiguous()
+        B = poses.shape[0]
+        fx, fy, cx, cy = [float(v) for v in intrinsics]
+        n_pix = H * W if inds is None else inds.shape[0]
+        rays_o = torch.empty(B, n_pix, 3, dtype=torch.float32, device=poses.device)
+        rays_d = torch.empty(B, n_pix, 3, dtype=torch.float32, device=poses.device)
+        lib = _lib.lib()
+        _lib.check(lib.ngp_get_rays(_lib.ptr(poses), B, fx, fy, cx, cy, H, W, _lib.ptr(inds), n_pix, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                                    _lib.stream()), "get_rays")
+        ctx.geom = (B, fx, fy, cx, cy, H, W, n_pix)
+        ctx.inds = inds
+        return rays_o, rays_d
+
+    @staticmethod
+    def backward(ctx, grad_o, grad_d):
+        B, fx, fy, cx, cy, H, W, n_pix = ctx.geom
+        go = None if grad_o is None else grad_o.float().contiguous()
+        gd = None if grad_d is None else grad_d.float().contiguous()
+        ref = go if go is not None else gd
+        grad_poses = torch.empty(B, 4, 4, dtype=torch.float32, device=ref.device)
+        _lib.check(_lib.lib().ngp_get_rays_backward(_lib.ptr(go), _lib.ptr(gd), B, fx, fy, cx, cy, H, W, _lib.ptr(ctx.inds), n_pix,
+                                                    _lib.ptr(grad_poses), _lib.stream()), "get_rays_backward")
+        return grad_poses, None, None, None, None
+
+
 def _rays_kernel(poses, intrinsics, H, W, inds):
     """poses [B,4,4] -> rays_o, rays_d [B, n_pix, 3] for pixel ids `inds` (int32 [n_pix], shared by all cameras) or all pixels."""
-    poses = poses.float().contiguous()
-    B = poses.shape[0]
-    fx, fy, cx, cy = [float(v) for v in intrinsics]
-    n_pix = H * W if inds is None else inds.shape[0]
-    rays_o = torch.empty(B, n_pix, 3, dtype=torch.float32, device=poses.device)
-    rays_d = torch.empty(B, n_pix, 3, dtype=torch.float32, device=poses.device)
-    lib = _lib.lib()
-    _lib.check(lib.ngp_get_rays(_lib.ptr(poses), B, fx, fy, cx, cy, H, W, _lib.ptr(inds), n_pix, _lib.ptr(rays_o), _lib.ptr(rays_d),
-                                _lib.stream()), "get_rays")
-    return rays_o, rays_d
+    return _RaysKernel.apply(poses, intrinsics, H, W, inds)
 
 
 @torch.amp.autocast("cuda", enabled=False)

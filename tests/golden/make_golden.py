@@ -82,7 +82,49 @@ def _make_raymarching_shim():
     def sph_from_ray(rays_o, rays_d, radius):
         raise NotImplementedError
 
+    def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
+                         align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3).float(), rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        M = N * max_steps
+        if not force_all_rays and mean_count > 0:
+            if align > 0:
+                mean_count += align - mean_count % align
+            M = mean_count
+        xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        rays = torch.empty(N, 3, dtype=torch.int32)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32)
+        O.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                           step_counter, int(perturb))
+        if force_all_rays or mean_count <= 0:
+            mm = int(step_counter[0])
+            if align > 0:
+                mm += align - mm % align
+            xyzs, dirs, deltas = xyzs[:mm], dirs[:mm], deltas[:mm]
+        return xyzs, dirs, deltas, rays
+
+    class _CompositeTrain(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, sigmas, rgbs, deltas, rays):
+            sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
+            M, N = sigmas.shape[0], rays.shape[0]
+            weights_sum, depth, image = torch.empty(N), torch.empty(N), torch.empty(N, 3)
+            O.composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image)
+            ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+            return weights_sum, depth, image
+
+        @staticmethod
+        def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+            sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+            M, N = sigmas.shape[0], rays.shape[0]
+            grad_sigmas, grad_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
+            O.composite_rays_train_backward(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum,
+                                            image, M, N, grad_sigmas, grad_rgbs)
+            return grad_sigmas, grad_rgbs, None, None
+
     m.near_far_from_aabb, m.march_rays, m.composite_rays, m.sph_from_ray = near_far_from_aabb, march_rays, composite_rays, sph_from_ray
+    m.march_rays_train, m.composite_rays_train = march_rays_train, _CompositeTrain.apply
     return m
 
 
@@ -187,12 +229,73 @@ def gen_run_cuda():
          **_weights(net))
 
 
+def gen_run_grad():
+    """d(rendered pixels)/d(pose) through get_rays -> render -> run, the derivative nav/estimator_helpers.py:191-225
+    (measurement_fn) and nav/quad_plot.py:223-249 take.  fp32, no autocast, 40 pixels of a 16x16 frame."""
+    bound, H, W = 2, 16, 16
+    net = _ref_network(bound, False, 48.0)
+    intr = SC.intrinsics(H, W)
+    pose = torch.from_numpy(SC.orbit_poses()[33:34].copy()).requires_grad_(True)
+    rays = ref_get_rays(pose, intr, H, W)
+    g = torch.Generator().manual_seed(3)
+    inds = torch.randperm(H * W, generator=g)[:40].sort().values
+    ro, rd = rays["rays_o"][:, inds], rays["rays_d"][:, inds]
+    ro.retain_grad()
+    rd.retain_grad()
+    out = net.render(ro, rd, staged=False, bg_color=1, perturb=False, num_steps=32, upsample_steps=0)
+    wts = torch.rand(1, 40, 3, generator=g)
+    wd = torch.rand(1, 40, generator=g)
+    loss = (out["image"] * wts).sum() + (out["depth"] * wd).sum()
+    for p_ in net.parameters():
+        p_.grad = None
+    loss.backward()
+    emb_g = net.encoder.embeddings.grad
+    nz = emb_g.abs().sum(-1).nonzero().squeeze(-1)
+    save("render_run_grad.npz", bound=bound, H=H, W=W, view=33, density_scale=48.0, table_seed=0, inds=inds.numpy(), wts=wts.numpy(),
+         wd=wd.numpy(), image=out["image"].detach().numpy(), depth=out["depth"].detach().numpy(), loss=float(loss),
+         grad_pose=pose.grad.numpy(), grad_rays_o=ro.grad.numpy(), grad_rays_d=rd.grad.numpy(),
+         emb_grad_rows=nz.numpy().astype(np.int32), emb_grad_vals=emb_g[nz].numpy(),
+         **{f"g_{k}": v for k, v in _grads(net).items()}, **_weights(net))
+
+
+def _grads(net):
+    return {f"sigma{i}": l.weight.grad.numpy() for i, l in enumerate(net.sigma_net)} | {
+        f"color{i}": l.weight.grad.numpy() for i, l in enumerate(net.color_net)}
+
+
+def gen_train_step():
+    """One Trainer.train_step worth of autograd (nerf/utils.py:404-487 -> renderer.py:293-327): run_cuda's TRAINING
+    branch = march_rays_train (perturb, PCG32 seed 42) -> network -> composite_rays_train, MSE against a target."""
+    bound, H, W = 2, 16, 16
+    sc = SC.StonehengeScene(H=H, W=W, bound=bound)
+    net = _ref_network(bound, True, 48.0).train()
+    net.density_bitfield = torch.from_numpy(sc.bitfield())
+    intr = SC.intrinsics(H, W)
+    pose = torch.from_numpy(SC.orbit_poses()[91:92].copy())
+    g = torch.Generator().manual_seed(4)
+    inds = torch.randperm(H * W, generator=g)[:24].sort().values
+    rays = ref_get_rays(pose, intr, H, W)
+    ro, rd = rays["rays_o"][:, inds], rays["rays_d"][:, inds]
+    target = torch.rand(1, 24, 3, generator=g)
+    out = net.render(ro, rd, staged=False, bg_color=1, perturb=True, force_all_rays=True, dt_gamma=0, max_steps=1024)
+    loss = ((out["image"] - target) ** 2).mean()
+    loss.backward()
+    emb_g = net.encoder.embeddings.grad
+    nz = emb_g.abs().sum(-1).nonzero().squeeze(-1)
+    save("train_step.npz", bound=bound, H=H, W=W, view=91, density_scale=48.0, table_seed=0, inds=inds.numpy(), target=target.numpy(),
+         bitfield_sha256=SC.bitfield_sha256(sc.bitfield()), image=out["image"].detach().numpy(), depth=out["depth"].detach().numpy(),
+         weights_sum=out["weights_sum"].detach().numpy(), loss=float(loss), emb_grad_rows=nz.numpy().astype(np.int32),
+         emb_grad_vals=emb_g[nz].numpy(), **{f"g_{k}": v for k, v in _grads(net).items()}, **_weights(net))
+
+
 if __name__ == "__main__":
     gen_get_rays()
     gen_grid_wrapper()
     gen_sh_wrapper()
     gen_run()
     gen_run_cuda()
+    gen_run_grad()
+    gen_train_step()
     # keep the reference tree pristine
     import shutil
     for dirpath, dirnames, _ in os.walk(REF):

@@ -116,3 +116,66 @@ def test_render_run_cuda_golden(device):
     err = np.abs(out16["image"].float().cpu().numpy() - f["image"])
     assert err.max() < 6e-3 and err.mean() < 5e-4, (err.max(), err.mean())     # fp16 table + fp16 MLP vs the fp32 reference run
     assert out16["sigmas"].shape == f["last_sigmas"].shape
+
+
+def _check_param_grads(net, f, rtol, atol_scale):
+    got = net.encoder.embeddings.grad.cpu().numpy()
+    rows, vals = f["emb_grad_rows"], f["emb_grad_vals"]
+    scale = np.abs(vals).max()
+    np.testing.assert_allclose(got[rows], vals, rtol=rtol, atol=atol_scale * scale)          # float atomics: summation order differs
+    mask = np.ones(got.shape[0], bool)
+    mask[rows] = False
+    assert np.abs(got[mask]).max() <= atol_scale * scale                                     # and nothing outside the touched rows
+    for name, layers in (("sigma", net.sigma_net), ("color", net.color_net)):
+        for i, l in enumerate(layers):
+            want = f[f"g_{name}{i}"]
+            np.testing.assert_allclose(l.weight.grad.cpu().numpy(), want, rtol=rtol, atol=atol_scale * np.abs(want).max())
+
+
+def test_render_run_pose_gradient_golden(device):
+    """d(rendered pixels)/d(pose) through get_rays(inds) -> render -> run on HIP operators (grid dy_dx + input
+    backward, SH backward, get_rays backward) against torch autograd through the reference's host Python."""
+    from nerfsafetyvalidation_amd import scene as SC
+    from nerfsafetyvalidation_amd.nerf.utils import get_rays
+    f = load("render_run_grad.npz")
+    net = _network(f, device, cuda_ray=False)
+    H, W = int(f["H"]), int(f["W"])
+    pose = _t(SC.orbit_poses()[int(f["view"]):int(f["view"]) + 1].copy(), device).requires_grad_(True)
+    rays = get_rays(pose, SC.intrinsics(H, W), H, W, inds=torch.from_numpy(f["inds"]))      # sparse: only the requested pixels
+    ro, rd = rays["rays_o"], rays["rays_d"]
+    ro.retain_grad()
+    rd.retain_grad()
+    out = net.render(ro, rd, staged=False, bg_color=1, perturb=False, num_steps=32, upsample_steps=0)
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), f["image"], rtol=0, atol=1e-4)
+    loss = (out["image"] * _t(f["wts"], device)).sum() + (out["depth"] * _t(f["wd"], device)).sum()
+    assert abs(float(loss.detach()) - float(f["loss"])) < 1e-3
+    loss.backward()
+    # gradients are sums of O(1e3) fp32 terms of mixed sign evaluated in a different order than the CPU fixture run
+    for got, key in ((ro.grad, "grad_rays_o"), (rd.grad, "grad_rays_d"), (pose.grad, "grad_pose")):
+        want = f[key]
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=2e-4 * np.abs(want).max())
+    assert torch.count_nonzero(pose.grad[0, 3]) == 0
+    _check_param_grads(net, f, rtol=2e-3, atol_scale=2e-4)
+
+
+def test_train_step_golden(device):
+    """run_cuda's TRAINING branch (march_rays_train with PCG32 jitter -> network -> composite_rays_train) and its
+    backward (composite backward, grid atomics, MLP) against the reference renderer driven on CPU."""
+    from nerfsafetyvalidation_amd import scene as SC
+    from nerfsafetyvalidation_amd.nerf.utils import get_rays
+    f = load("train_step.npz")
+    net = _network(f, device, cuda_ray=True).train()
+    H, W = int(f["H"]), int(f["W"])
+    sc = SC.StonehengeScene(H=H, W=W, bound=int(f["bound"]))
+    assert SC.bitfield_sha256(sc.bitfield()) == str(f["bitfield_sha256"])
+    net.density_bitfield.copy_(torch.from_numpy(sc.bitfield()).to(device))
+    pose = _t(SC.orbit_poses()[int(f["view"]):int(f["view"]) + 1].copy(), device)
+    rays = get_rays(pose, SC.intrinsics(H, W), H, W, inds=torch.from_numpy(f["inds"]))
+    out = net.render(rays["rays_o"], rays["rays_d"], staged=False, bg_color=1, perturb=True, force_all_rays=True, dt_gamma=0, max_steps=1024)
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), f["image"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), f["depth"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["weights_sum"].detach().cpu().numpy(), f["weights_sum"], rtol=0, atol=1e-4)
+    loss = ((out["image"] - _t(f["target"], device)) ** 2).mean()
+    assert abs(float(loss.detach()) - float(f["loss"])) < 1e-5
+    loss.backward()
+    _check_param_grads(net, f, rtol=2e-3, atol_scale=2e-4)
