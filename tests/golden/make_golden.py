@@ -288,6 +288,21 @@ def gen_train_step():
          emb_grad_vals=emb_g[nz].numpy(), **{f"g_{k}": v for k, v in _grads(net).items()}, **_weights(net))
 
 
+def gen_state_dict_keys():
+    """Names, shapes and dtypes of the reference model's state dict (what Trainer.save_checkpoint stores under 'model',
+    nerf/utils.py:938-998) for the configurations the rollout uses; a checkpoint-compatibility pin, no tensor data."""
+    import json
+    out = {}
+    for bound in (1, 2):
+        for cuda_ray in (False, True):
+            net = RefNetwork(encoding="hashgrid", bound=bound, cuda_ray=cuda_ray, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1)
+            out[f"bound{bound}_cuda_ray{int(cuda_ray)}"] = {k: [list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()}
+    path = os.path.join(HERE, "state_dict_keys.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print(f"wrote {path}")
+
+
 if __name__ == "__main__":
     gen_get_rays()
     gen_grid_wrapper()
@@ -296,6 +311,7 @@ if __name__ == "__main__":
     gen_run_cuda()
     gen_run_grad()
     gen_train_step()
+    gen_state_dict_keys()
     # keep the reference tree pristine
     import shutil
     for dirpath, dirnames, _ in os.walk(REF):

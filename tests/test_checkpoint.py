@@ -1,0 +1,81 @@
+"""Checkpoint interchange with the reference trainer and the Linear <-> FFMLP blob conversion (CPU, no GPU needed)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _net(bound=1, cuda_ray=True):
+    from nerfsafetyvalidation_amd.nerf.network import NeRFNetwork
+    return NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=cuda_ray, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1)
+
+
+@pytest.mark.parametrize("bound,cuda_ray", [(1, False), (1, True), (2, False), (2, True)])
+def test_state_dict_matches_reference_model(bound, cuda_ray):
+    """names / shapes / dtypes == the reference NeRFNetwork's state dict (fixture written by tests/golden/make_golden.py)"""
+    with open(os.path.join(G, "state_dict_keys.json")) as fh:
+        want = json.load(fh)[f"bound{bound}_cuda_ray{int(cuda_ray)}"]
+    got = {k: [list(v.shape), str(v.dtype)] for k, v in _net(bound, cuda_ray).state_dict().items()}
+    assert got == want
+
+
+def test_checkpoint_roundtrip_in_reference_layout(tmp_path):
+    from nerfsafetyvalidation_amd import checkpoint as CK
+    torch.manual_seed(3)
+    a = _net(1, True)
+    a.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    a.density_bitfield.random_(0, 255)
+    a.mean_count, a.mean_density = 4096, 0.37
+    path = CK.save_checkpoint(a, str(tmp_path / "checkpoints" / "ngp_ep0007.pth"), epoch=7, global_step=1234)
+    raw = torch.load(path, weights_only=True)                      # the trainer's dict layout (nerf/utils.py:943-976)
+    assert set(raw) == {"epoch", "global_step", "stats", "mean_count", "mean_density", "model"}
+    assert CK.latest_checkpoint(str(tmp_path / "checkpoints")) == path
+    b = _net(1, True)
+    missing, unexpected, meta = CK.load_checkpoint(b, path)
+    assert missing == [] and unexpected == [] and meta["epoch"] == 7 and meta["global_step"] == 1234
+    assert b.mean_count == 4096 and b.mean_density == 0.37
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    # `best` checkpoints drop the density grid but keep the bitfield (nerf/utils.py:987-988)
+    best = CK.save_checkpoint(a, str(tmp_path / "best.pth"), best=True)
+    c = _net(1, True)
+    missing, unexpected, _ = CK.load_checkpoint(c, best)
+    assert missing == ["density_grid"] and unexpected == []
+    assert torch.equal(c.density_bitfield, a.density_bitfield)
+    # a bare state dict is accepted too (nerf/utils.py:1012-1015)
+    torch.save(a.state_dict(), str(tmp_path / "bare.pth"))
+    d = _net(1, True)
+    assert CK.load_checkpoint(d, str(tmp_path / "bare.pth"))[:2] == ([], [])
+    assert torch.equal(d.encoder.embeddings, a.encoder.embeddings)
+
+
+def test_linear_to_ffmlp_blob_and_back():
+    from nerfsafetyvalidation_amd import checkpoint as CK
+    from oracle import driver as D
+    rng = np.random.default_rng(0)
+    ws = [torch.from_numpy(rng.uniform(-0.3, 0.3, s).astype(np.float32)) for s in [(64, 31), (64, 64), (64, 64), (3, 64)]]
+    blob, in_pad, out_dim, nl = CK.linear_weights_to_ffmlp_blob(ws)
+    assert (in_pad, out_dim, nl) == (32, 3, 3) and blob.numel() == 64 * (32 + 2 * 64 + 16)
+    back = CK.ffmlp_blob_to_linear_weights(blob, 32, 3, 64, 3)
+    assert torch.equal(back[0][:, :31], ws[0]) and torch.count_nonzero(back[0][:, 31]) == 0
+    assert all(torch.equal(b, w) for b, w in zip(back[1:], ws[1:]))
+    # the blob evaluates the same network: oracle FFMLP on zero-padded inputs == the plain fp16-rounded ReLU MLP
+    x = rng.uniform(-1, 1, (40, 31)).astype(np.float16)
+    xp = np.zeros((40, 32), np.float16)
+    xp[:, :31] = x
+    got = D.oracle_ffmlp(xp, blob.half().numpy(), 32, 64, 3)[:, :3].astype(np.float32)
+    h = x.astype(np.float64)
+    for k, w in enumerate(ws):
+        h = h @ w.half().double().numpy().T
+        if k + 1 < len(ws):
+            h = np.maximum(h, 0)
+        h = h.astype(np.float32).astype(np.float16).astype(np.float64)
+    assert np.array_equal(got, h.astype(np.float32))
+    with pytest.raises(ValueError):
+        CK.linear_weights_to_ffmlp_blob(ws[:2])
+    with pytest.raises(ValueError):
+        CK.linear_weights_to_ffmlp_blob([torch.zeros(48, 32), torch.zeros(48, 48), torch.zeros(3, 48)])
