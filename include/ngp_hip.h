@@ -256,6 +256,17 @@ NGP_API int ngp_render_uniform(const ngp_model* model, const float* rays_o, cons
                        float* image, float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs,
                        ngp_stream_t stream);
 
+/* ---------------- uncertainty/quantification/gaussian_approximation_density_uncertainty.py:24-51 ---------------- */
+
+/* Sufficient statistics of the Gaussian-approximation objective, one pass on the device instead of five global
+ * reductions + .item() per scipy.minimize evaluation.  c [n,3] per-sample colours (dtype code 0 = f32,
+ * 1 = f16), d [n] f32 per-sample densities, r [m] f32 rendered colour values.  stats (device, 8 doubles):
+ *   [0] sum c^2 d^2   [1] sum c d   [2] sum r   [3] m   [4] sum d   [5] sum d^2   [6] n   [7] 0
+ * accumulated in double in a fixed order (deterministic).  workspace: ngp_uq_stats_workspace() bytes of device memory. */
+NGP_API size_t ngp_uq_stats_workspace(void);
+NGP_API int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n, const float* r, uint64_t m, double* stats,
+                 void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+
 /* Diagnostics: when a device buffer of >= 8 uint64 is set, k_render_iter adds per-phase wave-cycle sums
  * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier).  NULL (default) = no
  * stamp instruction executes. */

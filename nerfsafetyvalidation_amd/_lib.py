@@ -67,6 +67,8 @@ SIGNATURES = {
     "ngp_ffmlp_free_splitk": [],
     "ngp_get_rays": [_vp, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _u32, _vp, _vp, _vp],
     "ngp_get_rays_backward": [_vp, _vp, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _u32, _vp, _vp],
+    "ngp_uq_stats_workspace": [],
+    "ngp_uq_stats": [_vp, _int, _vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _sz, _vp],
     "ngp_render_ctx_create": [_u32, C.POINTER(_vp)],
     "ngp_render_ctx_destroy": [_vp],
     "ngp_render_rays": [_vp, C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
@@ -80,7 +82,7 @@ SIGNATURES = {
     "ngp_prof_reset": [],
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
-_RESTYPES = {"ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz}
+_RESTYPES = {"ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
 
 _lib = None
 

@@ -85,6 +85,58 @@ static void prof_collect(ProfEntry& e) {
     e.events.clear();
 }
 
+// ---- uncertainty statistics (gaussian_approximation_density_uncertainty.py:24-51) -----------------------
+constexpr uint32_t kUqBlocks = 512, kUqThreads = 256;
+
+template <typename CT>
+__global__ void __launch_bounds__(kUqThreads) k_uq_partial(const CT* __restrict__ c, const float* __restrict__ d, uint64_t n,
+                                                           const float* __restrict__ r, uint64_t m, double* __restrict__ partial) {
+    __shared__ double red[5][kUqThreads / 64];
+    double acc[5] = {0, 0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * kUqThreads, t0 = (uint64_t)blockIdx.x * kUqThreads + threadIdx.x;
+    for (uint64_t i = t0; i < n; i += stride) {
+        const double dv = (double)d[i];
+        double sc = 0, sc2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double cv = (double)(float)c[i * 3 + k];
+            sc += cv;
+            sc2 += cv * cv;
+        }
+        acc[0] += sc2 * dv * dv;
+        acc[1] += sc * dv;
+        acc[3] += dv;
+        acc[4] += dv * dv;
+    }
+    for (uint64_t i = t0; i < m; i += stride) acc[2] += (double)r[i];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double v = 0;
+        for (uint32_t w = 0; w < kUqThreads / 64; w++) v += red[threadIdx.x][w];
+        partial[(size_t)blockIdx.x * 5 + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_uq_final(const double* __restrict__ partial, uint32_t blocks, uint64_t n, uint64_t m, double* __restrict__ stats) {
+    const uint32_t k = threadIdx.x;
+    if (k >= 5) return;
+    double v = 0;
+    for (uint32_t b = 0; b < blocks; b++) v += partial[(size_t)b * 5 + k];
+    const int slot[5] = {0, 1, 2, 4, 5};
+    stats[slot[k]] = v;
+    if (k == 0) {
+        stats[3] = (double)m;
+        stats[6] = (double)n;
+        stats[7] = 0;
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -98,6 +150,30 @@ int ngp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+size_t ngp_uq_stats_workspace(void) { return (size_t)kUqBlocks * 5 * sizeof(double); }
+
+int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n, const float* r, uint64_t m, double* stats, void* workspace,
+                 size_t workspace_bytes, ngp_stream_t stream) {
+    NGP_REQUIRE(stats && workspace, "uq_stats: null pointer");
+    NGP_REQUIRE((c && d) || n == 0, "uq_stats: null sample buffers");
+    NGP_REQUIRE(r || m == 0, "uq_stats: null rendered-colour buffer");
+    NGP_REQUIRE(workspace_bytes >= ngp_uq_stats_workspace(), "uq_stats: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                ngp_uq_stats_workspace());
+    NGP_REQUIRE(c_dtype == 0 || c_dtype == 1, "uq_stats: colour dtype must be 0 (f32) or 1 (f16)");
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t work = n > m ? n : m;
+    uint32_t blocks = (uint32_t)((work + kUqThreads - 1) / kUqThreads);
+    blocks = blocks < 1 ? 1 : blocks > kUqBlocks ? kUqBlocks : blocks;
+    if (c_dtype == 0)
+        k_uq_partial<float><<<blocks, kUqThreads, 0, s>>>((const float*)c, d, n, r, m, (double*)workspace);
+    else
+        k_uq_partial<_Float16><<<blocks, kUqThreads, 0, s>>>((const _Float16*)c, d, n, r, m, (double*)workspace);
+    int rc = check_launch("uq_stats");
+    if (rc) return rc;
+    k_uq_final<<<1, 64, 0, s>>>((const double*)workspace, blocks, n, m, stats);
+    return check_launch("uq_stats (final)");
 }
 
 int ngp_prof_enable(int on) {

@@ -214,3 +214,22 @@ def oracle_run(net, rays_o, rays_d, bound, density_scale, num_steps, min_near=0.
     image = (w[..., None] * rgb).sum(1) + (1 - ws)[:, None] * bg
     depth = (w * np.clip((z - nears[:, None]) / (fars - nears)[:, None], 0, 1)).sum(1)
     return dict(image=image, depth=depth, weights_sum=ws, aggregated_density=(w * sigma).sum(1), sigmas=sigma, rgbs=rgb)
+
+
+def oracle_uq_statistics(c, d, r):
+    """uncertainty/quantification/gaussian_approximation_density_uncertainty.py:24-36,46: the parameter-independent sums of
+    the objective and the initial guess, in float64.  c [N,T,3], d [N*T] (viewed [N,T,1], :21), r any shape."""
+    c = np.asarray(c, np.float64)
+    d = np.asarray(d, np.float64).reshape(c.shape[0], c.shape[1], -1)
+    r = np.asarray(r, np.float64)
+    return {"A": float(np.sum(c ** 2 * d ** 2)), "B": float(np.sum(c * d)), "R": float(np.mean(r)), "mean_d": float(np.mean(d)),
+            "std_d": float(np.std(d, ddof=1))}
+
+
+def oracle_uq_objective(c, d, r, params):
+    """:33-36 evaluated as written (float64)."""
+    c = np.asarray(c, np.float64)
+    d = np.asarray(d, np.float64).reshape(c.shape[0], c.shape[1], -1)
+    mu_d, sigma_d = params
+    den = np.sum(c ** 2 * sigma_d ** 2 * d ** 2)
+    return float(np.log(np.sum(c ** 2 * d ** 2 * sigma_d ** 2)) + (np.mean(np.asarray(r, np.float64)) - np.sum(c * mu_d * d)) ** 2 / den)

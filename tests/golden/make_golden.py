@@ -288,6 +288,22 @@ def gen_train_step():
          emb_grad_vals=emb_g[nz].numpy(), **{f"g_{k}": v for k, v in _grads(net).items()}, **_weights(net))
 
 
+def gen_uq():
+    """The reference's GaussianApproximationDensityUncertainty (objective at fixed parameters, initial guess) on seeded
+    sample tensors shaped like a render's rgbs / sigmas / image."""
+    from uncertainty.quantification.gaussian_approximation_density_uncertainty import GaussianApproximationDensityUncertainty as RefUQ
+    g = torch.Generator().manual_seed(21)
+    N, T = 37, 48
+    c = torch.rand(N, T, 3, generator=g)
+    d = torch.rand(N * T, generator=g) * 3.0 * (torch.rand(N * T, generator=g) > 0.6)
+    r = torch.rand(1, N, 3, generator=g)
+    uq = RefUQ(c, d, r)
+    params = np.array([[0.5, 1.0], [0.02, 0.3], [1.7, 2.5], [-0.4, 0.05]], np.float64)
+    obj = np.array([uq.objective(list(p_)) for p_ in params], np.float64)
+    save("uq_gaussian.npz", c=c.numpy(), d=d.numpy(), r=r.numpy(), params=params, objective=obj,
+         initial_guess=np.array([torch.mean(uq.d).item(), torch.std(uq.d).item()], np.float64))
+
+
 def gen_state_dict_keys():
     """Names, shapes and dtypes of the reference model's state dict (what Trainer.save_checkpoint stores under 'model',
     nerf/utils.py:938-998) for the configurations the rollout uses; a checkpoint-compatibility pin, no tensor data."""
@@ -312,6 +328,7 @@ if __name__ == "__main__":
     gen_run_grad()
     gen_train_step()
     gen_state_dict_keys()
+    gen_uq()
     # keep the reference tree pristine
     import shutil
     for dirpath, dirnames, _ in os.walk(REF):

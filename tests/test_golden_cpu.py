@@ -122,3 +122,14 @@ def test_train_forward_restatement_matches_reference_renderer():
     np.testing.assert_allclose(ws, f["weights_sum"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(img + (1 - ws)[:, None], f["image"][0], rtol=0, atol=2e-5)
     np.testing.assert_allclose(np.clip(dep - nears, 0, None) / (fars - nears), f["depth"][0], rtol=0, atol=2e-5)
+
+
+def test_uq_restatement_matches_reference_class():
+    """oracle_uq_* (float64) == the reference's GaussianApproximationDensityUncertainty evaluated in torch fp32 on CPU"""
+    f = load("uq_gaussian.npz")
+    st = Hh.oracle_uq_statistics(f["c"], f["d"], f["r"])
+    np.testing.assert_allclose([st["mean_d"], st["std_d"]], f["initial_guess"], rtol=1e-5)
+    for p, want in zip(f["params"], f["objective"]):
+        np.testing.assert_allclose(Hh.oracle_uq_objective(f["c"], f["d"], f["r"], p), want, rtol=2e-5, atol=1e-5)
+        closed = np.log(p[1] ** 2 * st["A"]) + (st["R"] - p[0] * st["B"]) ** 2 / (p[1] ** 2 * st["A"])
+        np.testing.assert_allclose(closed, want, rtol=2e-5, atol=1e-5)            # the sufficient-statistics form is the same function

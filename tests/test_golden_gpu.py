@@ -179,3 +179,20 @@ def test_train_step_golden(device):
     assert abs(float(loss.detach()) - float(f["loss"])) < 1e-5
     loss.backward()
     _check_param_grads(net, f, rtol=2e-3, atol_scale=2e-4)
+
+
+def test_uq_gaussian_golden(device):
+    """one-pass device statistics + closed-form objective against the reference class's values"""
+    from nerfsafetyvalidation_amd.uncertainty.quantification import GaussianApproximationDensityUncertainty
+    f = load("uq_gaussian.npz")
+    for half in (False, True):
+        c = _t(f["c"], device)
+        uq = GaussianApproximationDensityUncertainty(c.half() if half else c, _t(f["d"], device), _t(f["r"], device))
+        tol = 2e-3 if half else 2e-5
+        np.testing.assert_allclose([uq.stats["mean_d"], uq.stats["std_d"]], f["initial_guess"], rtol=1e-5)
+        for p, want in zip(f["params"], f["objective"]):
+            np.testing.assert_allclose(uq.objective(list(p)), want, rtol=tol, atol=tol)
+    mu, sg = uq.optimize()
+    assert np.isfinite(mu) and np.isfinite(sg)
+    again = GaussianApproximationDensityUncertainty(_t(f["c"], device), _t(f["d"], device), _t(f["r"], device))
+    assert again.stats == GaussianApproximationDensityUncertainty(_t(f["c"], device), _t(f["d"], device), _t(f["r"], device)).stats  # deterministic
