@@ -140,6 +140,7 @@ struct Dda {
     double Hd;
     bool h_pow2, const_dt;
     int level_dt0;
+    float t_fast_min;   // constant-step skips use a closed form for t >= this (see skip_const_dt)
     const uint8_t* grid;
 
     __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
@@ -160,6 +161,31 @@ struct Dda {
         // dt_gamma == 0 (the default): clamp(t * 0, dt_min, dt_max) == dt_min for every t, so the step and its mip level are constants
         const_dt = dt_gamma_ == 0.0f;
         level_dt0 = mip_from_dt(dt_min);
+        // dt_min = m * 2^(ed-23).  Added to a t of exponent e it is rounded to a multiple of ulp(t) = 2^(e-23); that rounding is a
+        // tie (and then depends on the parity of t) only in the one binade e = ed + ctz(m) + 1.  Everywhere above it the rounded
+        // step is a per-binade constant.
+        const uint32_t b = __float_as_uint(dt_min);
+        const uint32_t m = (b & 0x7FFFFFu) | 0x800000u;
+        t_fast_min = __uint_as_float(((b >> 23) + (uint32_t)__ffs((int)m) + 1u) << 23);
+    }
+
+    // `do { t += dt_min; } while (t < tt);` (:395-403 with a constant step) without the loop.  Inside one binade above the tie
+    // binade every addition advances t by the same d = fl(t + dt_min) - t exactly (t and d are multiples of ulp(t), the sums
+    // stay below the next power of two), so the loop ends at the smallest lattice point t1 + k*d >= tt.  k comes from an
+    // approximate quotient and is corrected by one step either way; fmaf(k, d, t1) is exact because the true value is
+    // representable.  Anything else (binade crossing, tiny t) falls back to the loop.
+    __device__ __forceinline__ void skip_const_dt(float& t, float tt) const {
+        const float t1 = t + dt_min;
+        if (!(t1 < tt)) { t = t1; return; }
+        const float d = t1 - t;
+        const float r = tt - t1;
+        float t2 = fmaf(ceilf(r * __builtin_amdgcn_rcpf(d)), d, t1);
+        if (t2 < tt) t2 += d;
+        else if (t2 - d >= tt) t2 -= d;
+        const bool same_binade = ((__float_as_uint(t2) ^ __float_as_uint(t)) >> 23) == 0;
+        if (same_binade && t >= t_fast_min) { t = t2; return; }
+        t = t1;
+        do { t += dt_min; } while (t < tt);
     }
 
     __device__ __forceinline__ int mip_from_pos(float x, float y, float z) const {   // :44-49
@@ -228,7 +254,7 @@ struct Dda {
             const float tz = fmaf(fmaf(0.5f, signf(dz), (float)nz + 0.5f) * rH * 2 - 1, mip_bound, -z) * rdz;
             const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
             if (const_dt) {
-                do { t += dt_min; } while (t < tt);
+                skip_const_dt(t, tt);
             } else {
                 do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
             }

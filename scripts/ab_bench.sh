@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of the fused renderer's march variants: flags bit0 = no march-ahead queue, bit1 = no coarse occupancy filter
-for f in 0 1 2 3; do
+# A/B of fused-renderer variants through bench.py --debug-flags (see ngp_debug_disable_march_queue); usage: ab_bench.sh "0 2 4"
+for f in ${1:-0 2 4}; do
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --debug-flags $f 2>/dev/null | tail -1 > /tmp/ab_$f.json
   python - "$f" <<'PY'
 import sys, json
