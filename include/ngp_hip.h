@@ -267,14 +267,14 @@ NGP_API size_t ngp_uq_stats_workspace(void);
 NGP_API int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n, const float* r, uint64_t m, double* stats,
                  void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
-/* Diagnostics: when a device buffer of >= 8 uint64 is set, k_render_iter adds per-phase wave-cycle sums
- * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier).  NULL (default) = no
+/* Diagnostics: when a device buffer of >= 16 uint64 is set, k_render_iter adds per-phase wave-cycle sums
+ * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier; [4..6] march lane statistics; [8] encode + sigma net, [9] colour net, [10] tiles, [11] samples in them).  NULL (default) = no
  * stamp instruction executes. */
 NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
 /* Diagnostics: uint32[N] device buffer receiving, per ray, an FNV-1a hash over the bit patterns of (dt, deltas[1]) of every
  * sample the fused renderer marched, in order (NULL = off).  Lets a test prove the fused path's sample sequence equal to
  * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 1 disables the coarse occupancy filter, bit 2 the
- * slow-ray grouping of the alive list (A/B experiments; bit 0 is reserved -- a march-ahead sample queue was measured slower and removed). */
+ * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 is reserved -- a march-ahead sample queue was measured slower and removed). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
 

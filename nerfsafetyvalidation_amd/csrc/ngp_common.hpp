@@ -141,6 +141,11 @@ struct Dda {
     bool h_pow2, const_dt;
     int level_dt0;
     float t_fast_min;   // constant-step skips use a closed form for t >= this (see skip_const_dt)
+    // fused renderer only (H a power of two): occupancy bits re-laid out x-fastest by k_build_linear (same cells, same bits)
+    const uint32_t* grid_lin;
+    uint32_t logH;
+    int sx, sy, sz;     // 1 where the direction component is >= +0 (signf == +1), else 0
+    float two_rH;
     const uint8_t* grid;
 
     __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
@@ -167,6 +172,15 @@ struct Dda {
         const uint32_t b = __float_as_uint(dt_min);
         const uint32_t m = (b & 0x7FFFFFu) | 0x800000u;
         t_fast_min = __uint_as_float(((b >> 23) + (uint32_t)__ffs((int)m) + 1u) << 23);
+    }
+
+    __device__ __forceinline__ void init_lin(const uint32_t* lin, uint32_t logH_) {
+        grid_lin = lin;
+        logH = logH_;
+        sx = (int)((__float_as_uint(dx) >> 31) ^ 1u);
+        sy = (int)((__float_as_uint(dy) >> 31) ^ 1u);
+        sz = (int)((__float_as_uint(dz) >> 31) ^ 1u);
+        two_rH = 2.0f * rH;
     }
 
     // `do { t += dt_min; } while (t < tt);` (:395-403 with a constant step) without the loop.  Inside one binade above the tie
@@ -224,6 +238,64 @@ struct Dda {
         // (testing the fine cell as well groups 3x more of the skipping rays -- march lane utilisation 66 % instead of 26 % --
         //  but was measured SLOWER overall: with the march that short, more waves gather at once and thrash L1/L2)
         return ((coarse[index >> 11] >> ((index >> 6) & 31u)) & 1u) == 0;
+    }
+
+    // ---- power-of-two H, linear bit layout (fused renderer) -------------------------------------------------------
+    // Same decisions and the same t as probe(), with cheaper arithmetic:
+    //  * clampf = v_med3_f32 (identical for non-NaN arguments);
+    //  * bit index level*H^3 + (z*H + y)*H + x into the re-laid-out copy instead of the Morton index into the original;
+    //  * the voxel face ((n + 0.5 + 0.5*sign(d)) / H) * 2 - 1 of :386-388 is (n + s) * (2/H) - 1 with s in {0, 1}: every
+    //    intermediate of the reference expression is exact when H is a power of two, so one fma gives the same float.
+    __device__ __forceinline__ int cell_pow2(float v, float mip_rbound) const {
+        return (int)__builtin_amdgcn_fmed3f(fmaf(v, mip_rbound, 1.0f) * halfH, 0.0f, Hm1);
+    }
+    __device__ __forceinline__ void locate_lin(float t, float& x, float& y, float& z, float& dt, int& level, float& mip_bound, int& nx, int& ny,
+                                               int& nz) const {
+        x = __builtin_amdgcn_fmed3f(fmaf(t, dx, ox), -bound, bound);
+        y = __builtin_amdgcn_fmed3f(fmaf(t, dy, oy), -bound, bound);
+        z = __builtin_amdgcn_fmed3f(fmaf(t, dz, oz), -bound, bound);
+        dt = const_dt ? dt_min : clampf(t * dt_gamma, dt_min, dt_max);
+        const int lp = mip_from_pos(x, y, z), ld = const_dt ? level_dt0 : mip_from_dt(dt);
+        level = lp > ld ? lp : ld;
+        const float pw = (float)(1 << level);
+        const bool use_pw = pw <= bound;
+        mip_bound = use_pw ? pw : bound;
+        const float mip_rbound = use_pw ? __uint_as_float((uint32_t)(127 - level) << 23) : rbound;
+        nx = cell_pow2(x, mip_rbound); ny = cell_pow2(y, mip_rbound); nz = cell_pow2(z, mip_rbound);
+    }
+    __device__ __forceinline__ uint32_t coarse_index_lin(int level, int nx, int ny, int nz) const {
+        const uint32_t lb = logH - 2;   // log2 of blocks per axis
+        return ((uint32_t)level << (3 * lb)) + ((((uint32_t)nz >> 2) << (2 * lb)) | (((uint32_t)ny >> 2) << lb) | ((uint32_t)nx >> 2));
+    }
+    __device__ __forceinline__ bool coarse_empty_at_lin(float t, const uint32_t* coarse) const {
+        float x, y, z, dt, mip_bound;
+        int level, nx, ny, nz;
+        locate_lin(t, x, y, z, dt, level, mip_bound, nx, ny, nz);
+        const uint32_t ci = coarse_index_lin(level, nx, ny, nz);
+        return ((coarse[ci >> 5] >> (ci & 31u)) & 1u) == 0;
+    }
+    __device__ __forceinline__ bool probe_lin(float& t, float& x, float& y, float& z, float& dt, const uint32_t* coarse) const {
+        float mip_bound;
+        int level, nx, ny, nz;
+        locate_lin(t, x, y, z, dt, level, mip_bound, nx, ny, nz);
+        const uint32_t ci = coarse_index_lin(level, nx, ny, nz);
+        bool occ = false;
+        if ((coarse[ci >> 5] >> (ci & 31u)) & 1u) {
+            const uint32_t fi = ((uint32_t)level << (3 * logH)) + (((uint32_t)nz << (2 * logH)) | ((uint32_t)ny << logH) | (uint32_t)nx);
+            occ = ((grid_lin[fi >> 5] >> (fi & 31u)) & 1u) != 0;
+        }
+        if (!occ) {
+            const float tx = fmaf(fmaf((float)(nx + sx), two_rH, -1.0f), mip_bound, -x) * rdx;
+            const float ty = fmaf(fmaf((float)(ny + sy), two_rH, -1.0f), mip_bound, -y) * rdy;
+            const float tz = fmaf(fmaf((float)(nz + sz), two_rH, -1.0f), mip_bound, -z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            if (const_dt) {
+                skip_const_dt(t, tt);
+            } else {
+                do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+            }
+        }
+        return occ;
     }
 
     // Probe at t. Occupied: returns true with x,y,z,dt set (caller advances t += dt).

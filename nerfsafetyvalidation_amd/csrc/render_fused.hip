@@ -44,6 +44,7 @@ constexpr int kThreads = kWaves * 64;     // 512
 constexpr int kWavesPerSimd = 4;          // two 512-thread workgroups per CU (LDS: 2 x ~72 KB)
 constexpr int kCh = 2;                    // march steps handled per sub-pass (n_step <= 8 is processed in chunks of kCh)
 constexpr int kSlots = 64 * kCh;          // sample slots per wave and sub-pass
+constexpr size_t kLinMaxBytes = 4u << 20;  // linear copy of the occupancy bitfield (C * H^3 / 8 bytes)
 constexpr size_t kCoarseMaxBytes = 8192;  // LDS budget for the coarse occupancy filter (C * H^3 / 64 bits)
 constexpr int kLookahead = 4;             // iterations the host may enqueue beyond the last status it has seen
 constexpr int kRing = 8;
@@ -183,6 +184,19 @@ __device__ __forceinline__ void sh4_quarter(uint32_t q, float x, float y, float 
     }
 }
 
+// fmaf(w, (float)half, acc) with the half taken from the low / high 16 bits of a packed table entry: one v_fma_mix_f32
+// (fp32 arithmetic, the conversion is part of the instruction).  hipcc otherwise converts both halves and uses v_pk_fma_f32.
+__device__ __forceinline__ float fma_mix_lo(float w, uint32_t packed, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float w, uint32_t packed, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(acc));
+    return r;
+}
+
 // density half: hash-grid encode + sigma net.  Returns sigma (meaningful in q == 0) and the sigma-net outputs 4q..4q+3 as fp16.
 template <bool GENERIC>
 __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
@@ -231,7 +245,10 @@ __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* W
     half8 feat;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        _Float16 a0 = (_Float16)0, a1 = (_Float16)0;
+        // The fused path accumulates the 8 corners in fp32 (one v_fma_mix_f32 per corner and feature) and rounds the feature
+        // to fp16 once; the grid_encode operator keeps the reference's c10::Half accumulation (8 roundings, :169-172) bit for
+        // bit.  The difference is below one fp16 ulp of the feature and inside the fused path's documented tolerance.
+        float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
             // w = ((1 * wx) * wy) * wz in the reference's order (:150-160); 1 * wx is exact
@@ -239,12 +256,11 @@ __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* W
             const float wy = (idx & 2) ? fr[i][1] : 1 - fr[i][1];
             const float wz = (idx & 4) ? fr[i][2] : 1 - fr[i][2];
             const float w = (wx * wy) * wz;
-            const half2v g = __builtin_bit_cast(half2v, raw[i][idx]);
-            a0 = a0 + mul_round_f16(w, g[0]);
-            a1 = a1 + mul_round_f16(w, g[1]);
+            a0 = fma_mix_lo(w, raw[i][idx], a0);
+            a1 = fma_mix_hi(w, raw[i][idx], a1);
         }
-        feat[2 * i] = oob ? (_Float16)0 : a0;
-        feat[2 * i + 1] = oob ? (_Float16)0 : a1;
+        feat[2 * i] = oob ? (_Float16)0 : (_Float16)a0;
+        feat[2 * i + 1] = oob ? (_Float16)0 : (_Float16)a1;
     }
 
     // ---- sigma net: 32 -> 64 (-> 64)* -> 16
@@ -292,6 +308,7 @@ __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds
 }
 
 // stage packed weights + level table into LDS (all threads of the block)
+__device__ uint32_t d_dbg_shrink = 0;  // diagnostics (ngp_debug_disable_march_queue bits 4-7): fold hashed levels into size >> n entries
 __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels& lv, _Float16* Wlds, LevelTab* lt) {
     const uint32_t n16 = (sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) / 8;  // 16-byte chunks
     const uint4* src = reinterpret_cast<const uint4*>(na.packed);
@@ -305,7 +322,7 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
         lt->size[l] = size;
         lt->a1[l] = lv.hashed[l] ? 2654435761u : lv.mul1[l];
         lt->a2[l] = lv.hashed[l] ? 805459861u : lv.mul2[l];
-        lt->mask[l] = lv.mode[l] == 1 ? size - 1 : 0xFFFFFFFFu;
+        lt->mask[l] = lv.mode[l] == 1 ? (size >> d_dbg_shrink) - 1 : 0xFFFFFFFFu;
         lt->flags[l] = (uint32_t)lv.hashed[l] | (lv.mode[l] == 2 ? 2u : 0u);
     }
     __syncthreads();
@@ -439,6 +456,42 @@ __global__ void __launch_bounds__(256) k_build_coarse(const unsigned long long* 
     if ((threadIdx.x & 63) == 0 && i < n_words) coarse[i >> 6] = m;
 }
 
+// Linear re-layout of the occupancy bits (power-of-two H): bit (level, z, y, x) of `lin` = bit level*H^3 + morton3D(x, y, z)
+// of the bitfield (raymarching.cu:381).  One thread per output word (32 consecutive x).
+__global__ void __launch_bounds__(256) k_build_linear(const uint8_t* __restrict__ bitfield, uint32_t cascade, uint32_t logH,
+                                                      uint32_t* __restrict__ lin) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t words_per_level = 1u << (3 * logH - 5);
+    if (w >= cascade * words_per_level) return;
+    const uint32_t level = w / words_per_level, c0 = (w % words_per_level) * 32;
+    const uint32_t H1 = (1u << logH) - 1;
+    const uint32_t x0 = c0 & H1, y = (c0 >> logH) & H1, z = c0 >> (2 * logH);
+    const uint32_t n = H1 + 1 < 32 ? H1 + 1 : 32;   // H < 32: a word spans several rows
+    uint32_t out = 0;
+    for (uint32_t i = 0; i < 32; i++) {
+        const uint32_t c = c0 + i;
+        const uint32_t xi = n == 32 ? x0 + i : (c & H1), yi = n == 32 ? y : ((c >> logH) & H1), zi = n == 32 ? z : (c >> (2 * logH));
+        const uint32_t m = (level << (3 * logH)) + morton3D_cell(xi, yi, zi);
+        out |= (uint32_t)((bitfield[m >> 3] >> (m & 7u)) & 1u) << i;
+    }
+    lin[w] = out;
+}
+
+// coarse bits in the same x-fastest order: bit (level, bz, by, bx) = any cell of the 4x4x4 block set
+__global__ void __launch_bounds__(256) k_build_coarse_linear(const unsigned long long* __restrict__ bitfield64, uint32_t cascade, uint32_t logH,
+                                                             unsigned long long* __restrict__ coarse) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lb = logH - 2, per_level = 1u << (3 * lb), B1 = (1u << lb) - 1;
+    bool any = false;
+    if (i < cascade * per_level) {
+        const uint32_t level = i / per_level, r = i % per_level;
+        const uint32_t bx = r & B1, by = (r >> lb) & B1, bz = r >> (2 * lb);
+        any = bitfield64[(size_t)level * per_level + morton3D_cell(bx, by, bz)] != 0ull;   // 64 Morton-consecutive cells = one block
+    }
+    const unsigned long long m = __ballot(any);
+    if ((threadIdx.x & 63) == 0 && i < cascade * per_level) coarse[i >> 6] = m;
+}
+
 // ------------------------------------------------------------------------------------------
 // render iteration
 // ------------------------------------------------------------------------------------------
@@ -463,6 +516,8 @@ struct RenderArgs {
     Pcg32 rng;
     const uint32_t* coarse;           // coarse occupancy (k_build_coarse), staged into LDS; NULL = unfiltered probes
     uint32_t coarse_words;            // its size in 32-bit words
+    const uint32_t* bitfield_lin;     // LIN kernels: x-fastest copy of the bitfield (k_build_linear) and log2(grid_size)
+    uint32_t log_grid;
     uint32_t* sample_hash;            // diagnostics (ngp_debug_set_sample_hash): per-ray FNV hash of the marched (dt, delta1) bit patterns
     unsigned long long* stamps;       // diagnostics only (ngp_debug_set_stamps): per-phase cycle sums; NULL in normal runs
 };
@@ -487,7 +542,8 @@ __device__ __forceinline__ void dump_row(const RenderArgs& ra, uint32_t entry, i
     }
 }
 
-template <bool GENERIC>
+// LIN: power-of-two grid with the linear copies of the occupancy bits (Dda::probe_lin); otherwise the Morton-order originals
+template <bool GENERIC, bool LIN>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
@@ -542,6 +598,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         if (active) {
             dda.init(ra.rays_o + (size_t)ray * 3, ra.rays_d + (size_t)ray * 3, ra.bitfield, na.bound, ra.dt_gamma, ra.max_steps, ra.cascade,
                      ra.grid_size);
+            if (LIN) dda.init_lin(ra.bitfield_lin, ra.log_grid);
             t_c = ra.rays_t[ray];      // composite_rays' t (:848) accumulates from the unperturbed value
             far = ra.fars[ray];
             t_march = t_c;
@@ -574,7 +631,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                 float x, y, z, dt;
                 while (t_march < far && cnt < want) {
                     n_probes++;
-                    if (dda.probe(t_march, x, y, z, dt, coarse)) {
+                    if (LIN ? dda.probe_lin(t_march, x, y, z, dt, coarse) : dda.probe(t_march, x, y, z, dt, coarse)) {
                         S.t[lane * kCh + cnt] = t_march;
                         S.dt[lane * kCh + cnt] = dt;
                         t_march += dt;
@@ -614,6 +671,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             for (uint32_t k = 0; k < cnt; k++) S.list[incl - cnt + k] = (uint16_t)((lane << 3) | k);
             wave_samples += total;
             const uint32_t n_tiles = (total + 15) / 16;
+            unsigned long long sub_a = 0, sub_b = 0, sub_n = 0, sub_f = 0;   // diagnostics only
             for (uint32_t tile = 0; tile < n_tiles; tile++) {
                 const uint32_t j = tile * 16 + c;
                 const bool valid = j < total;
@@ -626,12 +684,30 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                 const float y = clampf(fmaf(t, dy, oy), -na.bound, na.bound);
                 const float z = clampf(fmaf(t, dz, oz), -na.bound, na.bound);
                 float sg, r, g, b;
-                net_tile<GENERIC>(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
+                if (ra.stamps) {   // diagnostics: split the tile into encode+sigma net and colour net, count tile fill
+                    const unsigned long long ta = __builtin_amdgcn_s_memtime();
+                    _Float16 s16[4];
+                    net_density<GENERIC>(na, Wlds, *lt, lane, x, y, z, sg, s16);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    const unsigned long long tb = __builtin_amdgcn_s_memtime();
+                    net_color(na, Wlds, lane, dx, dy, dz, s16, r, g, b);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    const unsigned long long tc = __builtin_amdgcn_s_memtime();
+                    sub_a += tb - ta;
+                    sub_b += tc - tb;
+                    sub_n += 1;
+                    sub_f += min(16u, total - tile * 16);
+                } else {
+                    net_tile<GENERIC>(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
+                }
                 if (lane < 16 && valid) {
                     S.sig[slot] = na.density_scale * sg;   // renderer.py:365
                     S.rg[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)r) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)g) << 16);
                     S.b[slot] = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b);
                 }
+            }
+            if (ra.stamps && lane == 0) {
+                atomicAdd(ra.stamps + 8, sub_a); atomicAdd(ra.stamps + 9, sub_b); atomicAdd(ra.stamps + 10, sub_n); atomicAdd(ra.stamps + 11, sub_f);
             }
             NGP_STAMP(1)
             // ---- 3. composite (raymarching.cu:860-897), lane = ray
@@ -692,7 +768,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         // wave doing comparable work (measured lane utilisation of the march without this: 19 %).  The order of the alive
         // list does not enter any result (perturb == 0), so this is a pure scheduling decision.
         bool slow = false;
-        if (ra.sort_slow && survive) slow = t_c < far && dda.coarse_empty_at(t_c, coarse);
+        if (ra.sort_slow && survive) slow = t_c < far && (LIN ? dda.coarse_empty_at_lin(t_c, coarse) : dda.coarse_empty_at(t_c, coarse));
         const unsigned long long ball_f = __ballot(survive && !slow), ball_s = __ballot(survive && slow);
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         if (survive && !slow) ra.staging[(size_t)chunk * 64 + (uint32_t)__popcll(ball_f & lt_mask)] = ray;
@@ -894,6 +970,7 @@ struct ngp_render_ctx {
     uint32_t* chunk_count = nullptr;
     float* rays_t = nullptr;
     unsigned long long* coarse = nullptr;   // coarse occupancy bits (<= 8 KB)
+    uint32_t* grid_lin = nullptr;           // x-fastest copy of the occupancy bitfield (k_build_linear), allocated on first use
     float4* dump_rec = nullptr;             // lazily allocated: [max_rays][8]
     uint32_t* dump_iter = nullptr;          // [max_rays]
     Ctl* ctl = nullptr;          // device [2]
@@ -908,6 +985,7 @@ struct ngp_render_ctx {
 static unsigned long long* g_stamps = nullptr;
 static uint32_t* g_sample_hash = nullptr;
 static bool g_coarse_off = false;
+static bool g_lin_off = false;
 static bool g_sort_off = false;
 
 static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
@@ -972,7 +1050,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
-    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
+    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -1021,7 +1099,22 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const size_t cells = (size_t)model->cascade * model->grid_size * model->grid_size * model->grid_size;
     const size_t coarse_bytes = cells / 64 / 8;
     const bool use_coarse = !g_coarse_off && cells % 4096 == 0 && coarse_bytes <= kCoarseMaxBytes && ((uintptr_t)model->density_bitfield & 7) == 0;
-    if (use_coarse) {
+    // linear re-layout (cheaper DDA probes): power-of-two grid of at least 8^3 cells; bit 3 of the debug flags turns it off
+    const uint32_t Hg = model->grid_size;
+    uint32_t logH = 0;
+    while ((1u << logH) < Hg) logH++;
+    bool lin = use_coarse && !g_lin_off && (1u << logH) == Hg && Hg >= 8 && cells / 8 <= kLinMaxBytes;
+    if (lin && !ctx->grid_lin && hipMalloc(&ctx->grid_lin, kLinMaxBytes) != hipSuccess) lin = false;
+    if (lin) {
+        const uint32_t n_words = (uint32_t)(cells / 32), n_coarse = (uint32_t)(cells / 64);
+        k_build_linear<<<div_up(n_words, 256), 256, 0, s>>>(model->density_bitfield, model->cascade, logH, ctx->grid_lin);
+        k_build_coarse_linear<<<div_up(n_coarse, 256), 256, 0, s>>>((const unsigned long long*)model->density_bitfield, model->cascade, logH,
+                                                                     ctx->coarse);
+        ra.coarse = (const uint32_t*)ctx->coarse;
+        ra.coarse_words = (uint32_t)(coarse_bytes / 4);
+        ra.bitfield_lin = ctx->grid_lin;
+        ra.log_grid = logH;
+    } else if (use_coarse) {
         const uint32_t n_words = (uint32_t)(cells / 64);
         k_build_coarse<<<div_up(n_words, 256), 256, 0, s>>>((const unsigned long long*)model->density_bitfield, n_words, ctx->coarse);
         ra.coarse = (const uint32_t*)ctx->coarse;
@@ -1046,8 +1139,10 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const bool generic = needs_generic(lv);
@@ -1070,8 +1165,10 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.heads = ctx->heads + cur;
         {
             ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
-            if (generic) k_render_iter<true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else k_render_iter<false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            if (generic && lin) k_render_iter<true, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else if (generic) k_render_iter<true, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else if (lin) k_render_iter<false, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else k_render_iter<false, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1));
@@ -1136,6 +1233,9 @@ int ngp_debug_set_sample_hash(uint32_t* device_buf) {
 int ngp_debug_disable_march_queue(int off) {
     g_coarse_off = (off & 2) != 0;
     g_sort_off = (off & 4) != 0;
+    g_lin_off = (off & 8) != 0;
+    const uint32_t sh = (uint32_t)(off >> 4) & 15u;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d_dbg_shrink), &sh, 4);
     return NGP_OK;
 }
 

@@ -39,6 +39,8 @@ bytes_alg = B * 588
 print(json.dumps({"op": "grid_encode_forward f16 L16 F2", "B": B, "inputs": mode, "ms": round(ms, 4), "points_per_s": round(B / ms * 1e3),
                   "roofline": {"bound": "hbm", "achieved": round(bytes_alg / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(bytes_alg / ms / 1e6 / 8000.0, 4)}}))
+if os.environ.get("NGP_DBG_FLAGS"):
+    lib.ngp_debug_disable_march_queue(int(os.environ["NGP_DBG_FLAGS"]))   # A/B diagnostics (bits 4-7: fold the hashed levels)
 sc = StonehengeScene(H=64, W=64, bound=2); model = sc.build_model(dev); fm = model.fused_model()
 xyz = (x * 4 - 2).contiguous(); dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
 ms, _ = timed("network_forward", lambda: fm.network_forward(xyz, dirs), reps=10)

@@ -9,7 +9,7 @@ from nerfsafetyvalidation_amd.scene import StonehengeScene
 dev = torch.device('cuda:0'); lib = _lib.lib()
 sc = StonehengeScene(H=800, W=800, bound=2); model = sc.build_model(dev); model.return_last_tensors = "--last" in sys.argv
 poses = torch.from_numpy(sc.poses).to(dev)
-buf = torch.zeros(8, dtype=torch.int64, device=dev)
+buf = torch.zeros(16, dtype=torch.int64, device=dev)
 with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
     for v in (0, 1):
         r = get_rays(poses[v:v+1], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False)
@@ -20,3 +20,4 @@ with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
 b = buf.cpu().tolist(); tot = sum(b[:4])
 for n, v in zip(['march', 'encode+mlp tiles', 'composite', 'compaction+barrier'], b[:4]): print(f'{n:22s} {v:16d} {100*v/tot:6.2f} %')
 print(f"march passes {b[6]}: mean probes per lane-pass {b[5]/max(1,b[6])/64:.2f}, mean of per-wave max {b[4]/max(1,b[6]):.2f}  -> lane utilisation {b[5]/max(1,64*b[4]):.3f}")
+print(f"tiles {b[10]}: mean fill {b[11]/max(1,b[10]):.2f}/16; cycles per tile: encode+sigma {b[8]/max(1,b[10]):.0f}, colour {b[9]/max(1,b[10]):.0f}; whole tile phase per tile {b[1]/max(1,b[10]):.0f}")

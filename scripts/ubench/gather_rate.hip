@@ -14,6 +14,25 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 }
 
 // G lanes share a line.  contiguous: lanes [g*G, g*G+G) share; interleaved: lanes with equal (lane % (64/G)) share.
+// MODE: 0 plain, 1 relaxed agent-scope atomic load (sc1: served by L2, bypasses L1), 2 nontemporal (nt)
+template <int MODE>
+__global__ void __launch_bounds__(256) kmode(const uint8_t* __restrict__ table, uint32_t n_lines, int G, int iters, uint32_t* __restrict__ sink) {
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t grp = lane / G;
+    const uint32_t within = (mix(lane * 977u + 13u) % 32) * 4;
+    uint32_t acc = 0;
+    uint32_t h = mix(wave * 64u + grp + 1u);
+#pragma unroll 8
+    for (int i = 0; i < iters; i++) {
+        h = h * 1664525u + 1013904223u;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(table + (size_t)((h >> 8) % n_lines) * 128 + within);
+        if (MODE == 0) acc += *p;
+        if (MODE == 1) acc += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 2) acc += __builtin_nontemporal_load(p);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 template <int BYTES>
 __global__ void __launch_bounds__(256) k(const uint8_t* __restrict__ table, uint32_t n_lines, int G, int interleaved, int iters,
                                          uint32_t* __restrict__ sink) {
@@ -70,5 +89,24 @@ int main() {
                     printf("%-6d %-8zu %-4d %-12s %10.3f %14.1f %14.2f\n", bytes, sz >> 10, G, inter ? "interleaved" : "contiguous", ms, cyc,
                            (double)blocks * 4 * iters * 64 / (ms * 1e-3) / 1e9);
                 }
+    printf("\ncache-policy variants, 4-byte loads, 8 in flight per wave\n%-8s %-4s %-10s %10s %14s\n", "table", "G", "mode", "ms", "cyc/instr/CU");
+    const char* names[3] = {"plain", "sc1(atomic)", "nt"};
+    for (size_t sz : sizes)
+        for (int G : {1, 4})
+            for (int mode = 0; mode < 3; mode++) {
+                const uint32_t n_lines = (uint32_t)(sz / 128);
+                for (int rep = 0; rep < 2; rep++) {
+                    CK(hipEventRecord(a));
+                    if (mode == 0) kmode<0><<<blocks, 256>>>(table, n_lines, G, iters, sink);
+                    if (mode == 1) kmode<1><<<blocks, 256>>>(table, n_lines, G, iters, sink);
+                    if (mode == 2) kmode<2><<<blocks, 256>>>(table, n_lines, G, iters, sink);
+                    CK(hipEventRecord(b));
+                    CK(hipEventSynchronize(b));
+                }
+                float ms;
+                CK(hipEventElapsedTime(&ms, a, b));
+                const double instr_per_cu = (double)blocks * 4 * iters / cus;
+                printf("%-8zu %-4d %-10s %10.3f %14.1f\n", sz >> 10, G, names[mode], ms, ms * 1e-3 * mhz * 1e6 / instr_per_cu);
+            }
     return 0;
 }
