@@ -30,6 +30,7 @@
 // Numerics: identical expressions to the operator kernels (explicit fmaf, -ffp-contract=off).
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <string.h>
 
 #include "ngp_common.hpp"
 
@@ -795,15 +796,29 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
 // classes per chunk (fast: stored from the front, slow: stored from the back, see k_render_iter); the next list is
 // [all slow survivors in order | all fast survivors in order].  With no slow survivors this is the reference's stable
 // compaction rays_alive[rays_alive >= 0].
+// The loop state goes straight into the host's pinned, coherent status ring (no copy, no event): all fields first, then --
+// after a system-scope fence -- the sequence number the host polls for (`pad` = number of the iteration that produced it).
+__device__ __forceinline__ void publish_status(Ctl* host_slot, const Ctl& n, uint32_t seq) {
+    if (!host_slot) return;
+    host_slot->n_alive = n.n_alive; host_slot->n_step = n.n_step; host_slot->step = n.step; host_slot->done = n.done;
+    host_slot->iters = n.iters; host_slot->last_n_alive = n.last_n_alive; host_slot->last_n_step = n.last_n_step;
+    host_slot->samples_marched = n.samples_marched; host_slot->samples_slots = n.samples_slots;
+    __threadfence_system();
+    __hip_atomic_store(&host_slot->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ cur, Ctl* __restrict__ nxt, const int32_t* __restrict__ staging,
                                                          const uint32_t* __restrict__ chunk_count, int32_t* __restrict__ alive_out, uint32_t N,
                                                          uint32_t max_steps, const unsigned long long* __restrict__ stat_shards,
-                                                         QueueHeads* __restrict__ nxt_heads) {
+                                                         QueueHeads* __restrict__ nxt_heads, Ctl* __restrict__ host_slot, uint32_t seq) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
     const Ctl c = *cur;
     if (c.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = c;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *nxt = c;
+            publish_status(host_slot, c, seq);
+        }
         return;
     }
     const uint32_t n_chunks = (c.n_alive + 63) / 64;
@@ -863,6 +878,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         n.done = (n.n_alive == 0 || n.step >= max_steps) ? 1 : 0;
         *nxt = n;
         for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
+        publish_status(host_slot, n, seq);
     }
 }
 
@@ -977,7 +993,9 @@ struct ngp_render_ctx {
     unsigned long long* stat_shards = nullptr;
     QueueHeads* heads = nullptr;  // device [2]
     _Float16* packed = nullptr;  // device
-    Ctl* status = nullptr;       // pinned [kRing]
+    Ctl* status = nullptr;       // pinned, coherent [kRing]: written by k_render_compact, polled by the host
+    Ctl* status_dev = nullptr;   // the same ring as the device addresses it
+    uint32_t seq_base = 0;       // sequence numbers already used by earlier render calls (slots are matched by number)
     hipEvent_t ev[kRing];
     int num_cu = 256;
 };
@@ -1033,7 +1051,11 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
     ok &= hipMalloc(&c->heads, 2 * sizeof(QueueHeads)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
-    ok &= hipHostMalloc(&c->status, kRing * sizeof(Ctl), hipHostMallocDefault) == hipSuccess;
+    ok &= hipHostMalloc(&c->status, kRing * sizeof(Ctl), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) {
+        memset(c->status, 0, kRing * sizeof(Ctl));
+        ok &= hipHostGetDevicePointer((void**)&c->status_dev, c->status, 0) == hipSuccess;
+    }
     for (int i = 0; i < kRing; i++) ok &= hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1171,17 +1193,35 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             else k_render_iter<false, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
-                                                           ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1));
-        (void)hipMemcpyAsync(&ctx->status[launched % kRing], ctx->ctl + (cur ^ 1), sizeof(Ctl), hipMemcpyDeviceToHost, s);
-        (void)hipEventRecord(ctx->ev[launched % kRing], s);
+                                                           ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
+                                                           ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1);
         launched++;
         launches += 2;
         // consume every status that has already landed; block only when too far ahead
         while (known < launched) {
             const bool must_wait = launched - known >= (uint32_t)kLookahead;
-            if (must_wait) (void)hipEventSynchronize(ctx->ev[known % kRing]);
-            else if (hipEventQuery(ctx->ev[known % kRing]) != hipSuccess) break;
-            last = ctx->status[known % kRing];
+            volatile Ctl* slot = ctx->status + known % kRing;
+            const uint32_t want_seq = ctx->seq_base + known + 1;
+            if (slot->pad != want_seq) {
+                if (!must_wait) break;
+                uint32_t spins = 0;
+                while (slot->pad != want_seq) {
+                    if ((++spins & 0xFFFu) == 0) {   // every few thousand polls make sure the stream is still alive
+                        const hipError_t q = hipStreamQuery(s);
+                        if (q != hipSuccess && q != hipErrorNotReady) {
+                            set_error("render_rays: %s", hipGetErrorString(q));
+                            return NGP_ELAUNCH;
+                        }
+                        if (q == hipSuccess && slot->pad != want_seq) {   // everything ran, nothing was published: cannot happen
+                            set_error("render_rays: the device finished without publishing iteration %u", known);
+                            return NGP_ELAUNCH;
+                        }
+                    }
+                    __builtin_ia32_pause();
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            last = *const_cast<Ctl*>(slot);
             known++;
             ub = last.n_alive;
             if (last.done) { done = true; break; }
@@ -1191,6 +1231,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             return NGP_ELAUNCH;
         }
     }
+    ctx->seq_base += launched;
     if (ra.dump_rec && last.iters > 0) {
         const uint32_t nb = div_up(N, 256);
         k_dump_count<<<nb, 256, 0, s>>>(ctx->dump_iter, N, last.iters - 1, ctx->chunk_count);
