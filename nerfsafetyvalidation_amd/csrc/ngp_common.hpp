@@ -136,7 +136,7 @@ struct Pcg32 {
 // Follows raymarching.cu:357-404 (identical text at :431-483 and :757-813).
 struct Dda {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3f, Cf, Hf, Hm1, halfH;
+    float bound, rbound, dt_gamma, dt_min, dt_max, dt_c, rH, H3f, Cf, Hf, Hm1, halfH;
     double Hd;
     bool h_pow2, const_dt;
     int level_dt0;
@@ -163,13 +163,15 @@ struct Dda {
         h_pow2 = (H & (H - 1)) == 0;
         halfH = 0.5f * Hf;
         grid = g;
-        // dt_gamma == 0 (the default): clamp(t * 0, dt_min, dt_max) == dt_min for every t, so the step and its mip level are constants
+        // dt_gamma == 0 (the default): clamp(t * 0, dt_min, dt_max) = fminf(dt_max, fmaxf(0, dt_min)) (:26) for every t, so the step
+        // and its mip level are constants -- dt_min normally, dt_max when max_steps is so small that dt_min exceeds it
         const_dt = dt_gamma_ == 0.0f;
-        level_dt0 = mip_from_dt(dt_min);
-        // dt_min = m * 2^(ed-23).  Added to a t of exponent e it is rounded to a multiple of ulp(t) = 2^(e-23); that rounding is a
+        dt_c = fminf(dt_max, fmaxf(0.0f, dt_min));
+        level_dt0 = mip_from_dt(dt_c);
+        // dt_c = m * 2^(ed-23).  Added to a t of exponent e it is rounded to a multiple of ulp(t) = 2^(e-23); that rounding is a
         // tie (and then depends on the parity of t) only in the one binade e = ed + ctz(m) + 1.  Everywhere above it the rounded
         // step is a per-binade constant.
-        const uint32_t b = __float_as_uint(dt_min);
+        const uint32_t b = __float_as_uint(dt_c);
         const uint32_t m = (b & 0x7FFFFFu) | 0x800000u;
         t_fast_min = __uint_as_float(((b >> 23) + (uint32_t)__ffs((int)m) + 1u) << 23);
     }
@@ -183,13 +185,13 @@ struct Dda {
         two_rH = 2.0f * rH;
     }
 
-    // `do { t += dt_min; } while (t < tt);` (:395-403 with a constant step) without the loop.  Inside one binade above the tie
-    // binade every addition advances t by the same d = fl(t + dt_min) - t exactly (t and d are multiples of ulp(t), the sums
+    // `do { t += dt_c; } while (t < tt);` (:395-403 with a constant step) without the loop.  Inside one binade above the tie
+    // binade every addition advances t by the same d = fl(t + dt_c) - t exactly (t and d are multiples of ulp(t), the sums
     // stay below the next power of two), so the loop ends at the smallest lattice point t1 + k*d >= tt.  k comes from an
     // approximate quotient and is corrected by one step either way; fmaf(k, d, t1) is exact because the true value is
     // representable.  Anything else (binade crossing, tiny t) falls back to the loop.
     __device__ __forceinline__ void skip_const_dt(float& t, float tt) const {
-        const float t1 = t + dt_min;
+        const float t1 = t + dt_c;
         if (!(t1 < tt)) { t = t1; return; }
         const float d = t1 - t;
         const float r = tt - t1;
@@ -199,7 +201,7 @@ struct Dda {
         const bool same_binade = ((__float_as_uint(t2) ^ __float_as_uint(t)) >> 23) == 0;
         if (same_binade && t >= t_fast_min) { t = t2; return; }
         t = t1;
-        do { t += dt_min; } while (t < tt);
+        do { t += dt_c; } while (t < tt);
     }
 
     __device__ __forceinline__ int mip_from_pos(float x, float y, float z) const {   // :44-49
@@ -228,7 +230,7 @@ struct Dda {
         const float x = clampf(fmaf(t, dx, ox), -bound, bound);
         const float y = clampf(fmaf(t, dy, oy), -bound, bound);
         const float z = clampf(fmaf(t, dz, oz), -bound, bound);
-        const float dt = const_dt ? dt_min : clampf(t * dt_gamma, dt_min, dt_max);
+        const float dt = const_dt ? dt_c : clampf(t * dt_gamma, dt_min, dt_max);
         const int lp = mip_from_pos(x, y, z), ld = const_dt ? level_dt0 : mip_from_dt(dt);
         const int level = lp > ld ? lp : ld;
         const float pw = (float)(1 << level);
@@ -254,7 +256,7 @@ struct Dda {
         x = __builtin_amdgcn_fmed3f(fmaf(t, dx, ox), -bound, bound);
         y = __builtin_amdgcn_fmed3f(fmaf(t, dy, oy), -bound, bound);
         z = __builtin_amdgcn_fmed3f(fmaf(t, dz, oz), -bound, bound);
-        dt = const_dt ? dt_min : clampf(t * dt_gamma, dt_min, dt_max);
+        dt = const_dt ? dt_c : clampf(t * dt_gamma, dt_min, dt_max);
         const int lp = mip_from_pos(x, y, z), ld = const_dt ? level_dt0 : mip_from_dt(dt);
         level = lp > ld ? lp : ld;
         const float pw = (float)(1 << level);
@@ -306,7 +308,7 @@ struct Dda {
         x = clampf(fmaf(t, dx, ox), -bound, bound);
         y = clampf(fmaf(t, dy, oy), -bound, bound);
         z = clampf(fmaf(t, dz, oz), -bound, bound);
-        dt = const_dt ? dt_min : clampf(t * dt_gamma, dt_min, dt_max);
+        dt = const_dt ? dt_c : clampf(t * dt_gamma, dt_min, dt_max);
         const int lp = mip_from_pos(x, y, z), ld = const_dt ? level_dt0 : mip_from_dt(dt);
         const int level = lp > ld ? lp : ld;
         // mip_bound = min(2^level, bound); 1 / mip_bound is exact for the power of two (built from its exponent)

@@ -101,6 +101,31 @@ def test_march_rays_bit_exact(device, dt_gamma, perturb):
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("max_steps", [16, 48, 100, 4096])
+def test_march_rays_step_budget_bit_exact(device, max_steps):
+    """dt_min = 2*sqrt(3)/max_steps exceeds dt_max = 2*sqrt(3)*2^(C-1)/H for small budgets: the reference's clamp
+    (fminf(max, fmaxf(x, min)), raymarching.cu:26) then steps by dt_max.  Also a non-power-of-two and a very fine budget."""
+    from nerfsafetyvalidation_amd import raymarching
+    sc = _scene()
+    rays_o, rays_d = _rays(sc, view=12)
+    N = rays_o.shape[0]
+    bitfield = sc.bitfield()
+    aabb = np.array([-sc.bound] * 3 + [sc.bound] * 3, np.float32)
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    O.near_far_from_aabb(rays_o, rays_d, aabb, N, 0.2, nears, fars)
+    alive = np.arange(N, dtype=np.int32)
+    n_step = 4
+    M = N * n_step
+    M += 128 - M % 128
+    xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+    O.march_rays(N, n_step, alive, nears, rays_o, rays_d, sc.bound, 0.0, max_steps, sc.cascade, 128, bitfield, nears, fars, xyzs, dirs, deltas, 0)
+    assert (deltas[:, 0] > 0).sum() > 100
+    g = raymarching.march_rays(N, n_step, _t(alive, device), _t(nears, device), _t(rays_o, device), _t(rays_d, device), sc.bound,
+                               _t(bitfield, device), sc.cascade, 128, _t(nears, device), _t(fars, device), 128, False, 0.0, max_steps)
+    for got, want in zip(g, (xyzs, dirs, deltas)):
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("perturb", [False, True])
 def test_march_rays_train_bit_exact(device, perturb):
     from nerfsafetyvalidation_amd import raymarching
