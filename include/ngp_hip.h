@@ -273,8 +273,8 @@ NGP_API int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n,
 NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
 /* Diagnostics: uint32[N] device buffer receiving, per ray, an FNV-1a hash over the bit patterns of (dt, deltas[1]) of every
  * sample the fused renderer marched, in order (NULL = off).  Lets a test prove the fused path's sample sequence equal to
- * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 1 disables the coarse occupancy filter, bit 2 the
- * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 is reserved -- a march-ahead sample queue was measured slower and removed). */
+ * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 0 / bit 1 disable the coarse occupancy filter, bit 2 the
+ * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
 

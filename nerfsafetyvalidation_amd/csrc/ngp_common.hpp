@@ -146,6 +146,8 @@ struct Dda {
     uint32_t logH;
     int sx, sy, sz;     // 1 where the direction component is >= +0 (signf == +1), else 0
     float two_rH;
+    float jump_guard;   // absolute part of the rounding allowance of a block-exit time (see jump_block)
+    bool block_jump;    // leave empty 4x4x4 blocks in one step (A/B switch)
     const uint8_t* grid;
 
     __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
@@ -176,13 +178,15 @@ struct Dda {
         t_fast_min = __uint_as_float(((b >> 23) + (uint32_t)__ffs((int)m) + 1u) << 23);
     }
 
-    __device__ __forceinline__ void init_lin(const uint32_t* lin, uint32_t logH_) {
+    __device__ __forceinline__ void init_lin(const uint32_t* lin, uint32_t logH_, bool block_jump_) {
         grid_lin = lin;
+        block_jump = block_jump_;
         logH = logH_;
         sx = (int)((__float_as_uint(dx) >> 31) ^ 1u);
         sy = (int)((__float_as_uint(dy) >> 31) ^ 1u);
         sz = (int)((__float_as_uint(dz) >> 31) ^ 1u);
         two_rH = 2.0f * rH;
+        jump_guard = (fabsf(rdx) + fabsf(rdy) + fabsf(rdz)) * bound * 9.5367431640625e-7f;   // 2^-20
     }
 
     // `do { t += dt_c; } while (t < tt);` (:395-403 with a constant step) without the loop.  Inside one binade above the tie
@@ -276,6 +280,44 @@ struct Dda {
         const uint32_t ci = coarse_index_lin(level, nx, ny, nz);
         return ((coarse[ci >> 5] >> (ci & 31u)) & 1u) == 0;
     }
+    // Leaving an EMPTY 4x4x4 block in one step.  The reference walks it cell by cell (:386-403): from a lattice point in an empty
+    // cell it goes to the first lattice point at or beyond that cell's exit, and so on; every point it visits inside the block
+    // is empty, so nothing is sampled there, and the walk leaves through a face of the last cell that is also a face of the
+    // block -- at the first lattice point >= T*, the exit time of the BLOCK.  T* evaluated here and the reference's last-cell exit
+    // are the same plane crossing rounded differently, so the shortcut is taken only when no lattice point lies within a
+    // generous rounding allowance of T* (then both pick the same point) and the constant-step lattice is exact (one binade,
+    // see skip_const_dt); otherwise the caller falls back to the cell walk.  The block must also be "pure": every position in
+    // it has to select this cascade level, which can fail only above the step-size level where the block may reach into the
+    // next finer cascade's cube.
+    __device__ __forceinline__ bool jump_block(float& t, float x, float y, float z, int level, float mip_bound, int nx, int ny, int nz) const {
+        const float bx = fmaf((float)((nx & ~3) + 4 * sx), two_rH, -1.0f), by = fmaf((float)((ny & ~3) + 4 * sy), two_rH, -1.0f),
+                    bz = fmaf((float)((nz & ~3) + 4 * sz), two_rH, -1.0f);
+        if (level > level_dt0) {
+            if (mip_bound != (float)(1 << level)) return false;   // top cascade of a non-power-of-two bound: units differ, walk the cells
+            // distance of the block from the origin in the max norm, in units of mip_bound: pure iff >= 1/2 (the finer cube's half size)
+            const float cell4 = 4.0f * two_rH;
+            const float ox_ = sx ? bx - cell4 : bx, oy_ = sy ? by - cell4 : by, oz_ = sz ? bz - cell4 : bz;   // low faces
+            const float mx = (ox_ <= 0.0f && ox_ + cell4 >= 0.0f) ? 0.0f : fminf(fabsf(ox_), fabsf(ox_ + cell4));
+            const float my = (oy_ <= 0.0f && oy_ + cell4 >= 0.0f) ? 0.0f : fminf(fabsf(oy_), fabsf(oy_ + cell4));
+            const float mz = (oz_ <= 0.0f && oz_ + cell4 >= 0.0f) ? 0.0f : fminf(fabsf(oz_), fabsf(oz_ + cell4));
+            if (fmaxf(mx, fmaxf(my, mz)) < 0.5f) return false;
+        }
+        const float tx = fmaf(bx, mip_bound, -x) * rdx, ty = fmaf(by, mip_bound, -y) * rdy, tz = fmaf(bz, mip_bound, -z) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        const float t1 = t + dt_c;
+        if (!(t1 < tt)) return false;
+        const float d = t1 - t;
+        float t2 = fmaf(ceilf((tt - t1) * __builtin_amdgcn_rcpf(d)), d, t1);
+        if (t2 < tt) t2 += d;
+        else if (t2 - d >= tt) t2 -= d;
+        const float guard = fmaf(t2, 9.5367431640625e-7f, jump_guard);
+        const bool clear = (t2 - tt) > guard && (tt - (t2 - d)) > guard;   // false for NaN / infinite allowances as well
+        const bool same_binade = ((__float_as_uint(t2) ^ __float_as_uint(t)) >> 23) == 0;
+        if (!(clear && same_binade && t >= t_fast_min)) return false;
+        t = t2;
+        return true;
+    }
+
     __device__ __forceinline__ bool probe_lin(float& t, float& x, float& y, float& z, float& dt, const uint32_t* coarse) const {
         float mip_bound;
         int level, nx, ny, nz;
@@ -285,6 +327,8 @@ struct Dda {
         if ((coarse[ci >> 5] >> (ci & 31u)) & 1u) {
             const uint32_t fi = ((uint32_t)level << (3 * logH)) + (((uint32_t)nz << (2 * logH)) | ((uint32_t)ny << logH) | (uint32_t)nx);
             occ = ((grid_lin[fi >> 5] >> (fi & 31u)) & 1u) != 0;
+        } else if (const_dt && block_jump && jump_block(t, x, y, z, level, mip_bound, nx, ny, nz)) {
+            return false;
         }
         if (!occ) {
             const float tx = fmaf(fmaf((float)(nx + sx), two_rH, -1.0f), mip_bound, -x) * rdx;

@@ -519,6 +519,7 @@ struct RenderArgs {
     uint32_t coarse_words;            // its size in 32-bit words
     const uint32_t* bitfield_lin;     // LIN kernels: x-fastest copy of the bitfield (k_build_linear) and log2(grid_size)
     uint32_t log_grid;
+    uint32_t block_jump;              // LIN kernels: leave empty 4x4x4 blocks in one step (Dda::jump_block)
     uint32_t* sample_hash;            // diagnostics (ngp_debug_set_sample_hash): per-ray FNV hash of the marched (dt, delta1) bit patterns
     unsigned long long* stamps;       // diagnostics only (ngp_debug_set_stamps): per-phase cycle sums; NULL in normal runs
 };
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         if (active) {
             dda.init(ra.rays_o + (size_t)ray * 3, ra.rays_d + (size_t)ray * 3, ra.bitfield, na.bound, ra.dt_gamma, ra.max_steps, ra.cascade,
                      ra.grid_size);
-            if (LIN) dda.init_lin(ra.bitfield_lin, ra.log_grid);
+            if (LIN) dda.init_lin(ra.bitfield_lin, ra.log_grid, ra.block_jump != 0);
             t_c = ra.rays_t[ray];      // composite_rays' t (:848) accumulates from the unperturbed value
             far = ra.fars[ray];
             t_march = t_c;
@@ -1004,6 +1005,7 @@ static unsigned long long* g_stamps = nullptr;
 static uint32_t* g_sample_hash = nullptr;
 static bool g_coarse_off = false;
 static bool g_lin_off = false;
+static bool g_jump_off = false;
 static bool g_sort_off = false;
 
 static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
@@ -1136,6 +1138,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.coarse_words = (uint32_t)(coarse_bytes / 4);
         ra.bitfield_lin = ctx->grid_lin;
         ra.log_grid = logH;
+        ra.block_jump = g_jump_off ? 0u : 1u;
     } else if (use_coarse) {
         const uint32_t n_words = (uint32_t)(cells / 64);
         k_build_coarse<<<div_up(n_words, 256), 256, 0, s>>>((const unsigned long long*)model->density_bitfield, n_words, ctx->coarse);
@@ -1275,6 +1278,7 @@ int ngp_debug_disable_march_queue(int off) {
     g_coarse_off = (off & 2) != 0;
     g_sort_off = (off & 4) != 0;
     g_lin_off = (off & 8) != 0;
+    g_jump_off = (off & 1) != 0;
     const uint32_t sh = (uint32_t)(off >> 4) & 15u;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(d_dbg_shrink), &sh, 4);
     return NGP_OK;

@@ -161,6 +161,35 @@ def test_fused_handles_edge_cases(setup, device):
     assert s_f["iterations"] == s_u["iterations"] and s_f["samples_slots"] == s_u["samples_slots"]
 
 
+def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
+    """The fused DDA's shortcuts (x-fastest bit layout, one-step exit from empty 4x4x4 blocks) against its plain cell walk:
+    same network, so every ray's (dt, delta) sample sequence hash and the image must be IDENTICAL, not merely close."""
+    from nerfsafetyvalidation_amd import _lib
+    sc, model, _ = setup
+    model.fused = True
+    lib = _lib.lib()
+    ro, rd = Hh.pinhole_rays(sc.poses[57], sc.intrinsics, sc.H, sc.W)
+    N = ro.shape[0]
+    outs = {}
+    try:
+        for flags in (0, 1, 8):          # all shortcuts / no block jump / Morton-order probes (no linear layout, no jump)
+            lib.ngp_debug_disable_march_queue(flags)
+            h = torch.zeros(N, dtype=torch.int32, device=device)
+            lib.ngp_debug_set_sample_hash(h.data_ptr())
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                img = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False)["image"].float()
+            torch.cuda.synchronize()
+            outs[flags] = (h.clone(), img.clone(), dict(model.last_render_stats))
+    finally:
+        lib.ngp_debug_set_sample_hash(None)
+        lib.ngp_debug_disable_march_queue(0)
+    for flags in (1, 8):
+        assert torch.equal(outs[0][0], outs[flags][0]), flags
+        assert torch.equal(outs[0][1], outs[flags][1]), flags
+        assert outs[0][2]["samples_marched"] == outs[flags][2]["samples_marched"]
+    assert outs[0][2]["samples_marched"] > 10000
+
+
 def test_linear_backbone_fused_vs_operator_loop(device):
     """nerf/network.py backbone (nn.Linear under autocast = library GEMMs) vs the fused kernel fed its padded weights"""
     sc = _scene()
