@@ -33,7 +33,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--size", type=int, default=800, help="frame edge (800 = the named workload)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-stride", type=int, default=16, help="cpu_baseline renders rays[::stride] of view 0")
+    p.add_argument("--cpu-stride", type=int, default=2, help="cpu_baseline renders rays[::stride] of view 0")
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the flow)")
@@ -51,7 +51,7 @@ def pmc_traffic_per_launch():
         with open(path) as fh:
             k = next(v for name, v in json.load(fh).items() if "k_render_iter" in name)
         kb = 2.0 * k["FETCH_SIZE"]["per_launch"] + k["WRITE_SIZE"]["per_launch"]    # both counters are in KiB
-        return {"bytes_per_launch": round(kb * 1024.0), "source": "profiles/r01_pmc_latest.json (FETCH_SIZE x2 + WRITE_SIZE)"}
+        return round(kb * 1024.0)
     except (OSError, StopIteration, KeyError, ValueError):
         return None
 
@@ -145,7 +145,8 @@ def main():
                 achieved = algo_bytes / (ms.value * 1e-3) / 1e9
                 roof = {"kernel": "k_render_iter (fused march+hashgrid+MLPs+composite)", "bound": "hbm",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic_per_launch(), "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
+                        "traffic": pmc_traffic_per_launch(), "traffic_unit": "bytes per launch (profiles/r01_pmc_latest.json: FETCH_SIZE x2 + WRITE_SIZE)",
+                        "achieved_bytes_per_launch": round(algo_bytes / n_launch.value), "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
                         "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
                         "algorithmic_bytes_per_sample": TABLE_BYTES_PER_SAMPLE, "algorithmic_bytes_per_ray_iteration": RAY_BYTES_PER_RAY_ITER}
 
