@@ -14,9 +14,9 @@ import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-def _scene(H=64, W=64):
+def _scene(H=64, W=64, bound=2):
     from nerfsafetyvalidation_amd.scene import StonehengeScene
-    return StonehengeScene(H=H, W=W, bound=2)
+    return StonehengeScene(H=H, W=W, bound=bound)
 
 
 def _t(x, device):
@@ -188,6 +188,36 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
         assert torch.equal(outs[0][1], outs[flags][1]), flags
         assert outs[0][2]["samples_marched"] == outs[flags][2]["samples_marched"]
     assert outs[0][2]["samples_marched"] > 10000
+
+
+@pytest.mark.parametrize("bound,dt_gamma,perturb,n_rays,max_steps", [
+    (1, 0.0, False, 3000, 1024),        # one cascade (the Lego setting): every DDA shortcut at level 0 only
+    (2, 1.0 / 128, False, 2500, 1024),  # cone stepping: no constant-step lattice, cell walk + step loop
+    (2, 0.0, True, 2111, 1024),         # jitter: the alive list keeps the reference's order (the jitter is seeded with the list index)
+    (1, 1.0 / 256, True, 1000, 512),
+    (2, 0.0, False, 4096, 100),         # non-power-of-two step budget
+])
+def test_fused_vs_operator_loop_across_configurations(device, bound, dt_gamma, perturb, n_rays, max_steps):
+    """The fused renderer against this repo's own operator-by-operator loop (each operator bit-exact with the oracle) on
+    settings the headline bench does not touch: schedule identical up to fp16-MLP termination noise, images within it."""
+    sc = _scene(bound=bound)
+    model = sc.build_model(device)
+    ro, rd = Hh.pinhole_rays(sc.poses[21], sc.intrinsics, sc.H, sc.W)
+    ro, rd = ro[:n_rays], rd[:n_rays]
+    out = {}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        for fused in (False, True):
+            model.fused = fused
+            r = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=perturb, dt_gamma=dt_gamma, max_steps=max_steps)
+            out[fused] = (r["image"].float().clone(), r["depth"].float().clone(), dict(model.last_render_stats))
+    (ia, da, sa), (ib, db, sb) = out[False], out[True]
+    assert sa["samples_slots"] > 0
+    assert abs(sa["iterations"] - sb["iterations"]) <= 1
+    assert abs(sa["samples_slots"] - sb["samples_slots"]) <= 0.004 * sa["samples_slots"] + 16
+    d = (ia - ib).abs()
+    assert d.max().item() < 6e-3 and d.mean().item() < 3e-4, (d.max().item(), d.mean().item())
+    dd = (da - db).abs()
+    assert dd.max().item() < 2e-2 and dd.mean().item() < 5e-4, (dd.max().item(), dd.mean().item())
 
 
 def test_linear_backbone_fused_vs_operator_loop(device):
