@@ -134,17 +134,16 @@ def dtype_code(t):
     raise RuntimeError(f"unsupported dtype {t.dtype}: the grid encoder supports float32 and float16")
 
 
-_host_i32_cache = {}
-
-
 def host_i32(t):
-    """int32 host copy of a small device tensor (e.g. GridEncoder.offsets), cached by storage identity + version."""
-    key = (t.data_ptr(), t._version, t.numel(), str(t.device))
-    arr = _host_i32_cache.get(key)
-    if arr is None:
-        vals = t.detach().to("cpu", torch.int32).tolist()
-        arr = (C.c_int32 * len(vals))(*vals)
-        if len(_host_i32_cache) > 64:
-            _host_i32_cache.clear()
-        _host_i32_cache[key] = arr
+    """int32 host copy of a small device tensor (e.g. GridEncoder.offsets), cached ON the tensor object and keyed by its
+    version counter.  (A cache keyed by data_ptr is wrong: the allocator hands a freed tensor's address to the next model.)"""
+    cached = getattr(t, "_ngp_host_i32", None)
+    if cached is not None and cached[0] == t._version and cached[1] == t.data_ptr():
+        return cached[2]
+    vals = t.detach().to("cpu", torch.int32).tolist()
+    arr = (C.c_int32 * len(vals))(*vals)
+    try:
+        t._ngp_host_i32 = (t._version, t.data_ptr(), arr)
+    except AttributeError:
+        pass
     return arr

@@ -797,21 +797,20 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
 // classes per chunk (fast: stored from the front, slow: stored from the back, see k_render_iter); the next list is
 // [all slow survivors in order | all fast survivors in order].  With no slow survivors this is the reference's stable
 // compaction rays_alive[rays_alive >= 0].
-// The loop state goes straight into the host's pinned, coherent status ring (no copy, no event): all fields first, then --
-// after a system-scope fence -- the sequence number the host polls for (`pad` = number of the iteration that produced it).
-__device__ __forceinline__ void publish_status(Ctl* host_slot, const Ctl& n, uint32_t seq) {
+// What the host needs while it enqueues iterations ahead -- how many rays are left and whether the loop has ended -- goes
+// straight into its pinned, coherent status ring as ONE 64-bit word (sequence number << 32 | done << 31 | n_alive), written
+// with a relaxed system-scope store: no copy, no event, and no release fence (a fence writes the XCD's L2 back, ~10 us at the
+// end of this short kernel).  Everything else the host reads from the device state after the loop.
+__device__ __forceinline__ void publish_status(unsigned long long* host_slot, const Ctl& n, uint32_t seq) {
     if (!host_slot) return;
-    host_slot->n_alive = n.n_alive; host_slot->n_step = n.n_step; host_slot->step = n.step; host_slot->done = n.done;
-    host_slot->iters = n.iters; host_slot->last_n_alive = n.last_n_alive; host_slot->last_n_step = n.last_n_step;
-    host_slot->samples_marched = n.samples_marched; host_slot->samples_slots = n.samples_slots;
-    __threadfence_system();
-    __hip_atomic_store(&host_slot->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long w = ((unsigned long long)seq << 32) | ((unsigned long long)(n.done ? 1u : 0u) << 31) | (n.n_alive & 0x7FFFFFFFu);
+    __hip_atomic_store(host_slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ cur, Ctl* __restrict__ nxt, const int32_t* __restrict__ staging,
                                                          const uint32_t* __restrict__ chunk_count, int32_t* __restrict__ alive_out, uint32_t N,
                                                          uint32_t max_steps, const unsigned long long* __restrict__ stat_shards,
-                                                         QueueHeads* __restrict__ nxt_heads, Ctl* __restrict__ host_slot, uint32_t seq) {
+                                                         QueueHeads* __restrict__ nxt_heads, unsigned long long* __restrict__ host_slot, uint32_t seq) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
     const Ctl c = *cur;
@@ -912,9 +911,10 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
 // The reference's alive list is always ascending in ray id (stable compaction of arange(N)), so row r of its last
 // iteration belongs to the r-th smallest ray id that was alive then.  Three small launches after the loop: per-block counts
 // of rays stamped with the last iteration, a one-block scan, and the scatter of the per-ray records.
-__global__ void __launch_bounds__(256) k_dump_count(const uint32_t* __restrict__ dump_iter, uint32_t N, uint32_t last_iter,
+__global__ void __launch_bounds__(256) k_dump_count(const uint32_t* __restrict__ dump_iter, uint32_t N, const Ctl* __restrict__ fin_state,
                                                      uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t ws[4];
+    const uint32_t last_iter = fin_state->iters - 1;   // iters == 0 (nothing ran): the gather kernel returns at once
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     const bool f = n < N && dump_iter[n] == last_iter;
     const uint32_t c = (uint32_t)__popcll(__ballot(f));
@@ -949,12 +949,14 @@ __global__ void __launch_bounds__(1024) k_dump_scan(uint32_t* __restrict__ block
     }
 }
 __global__ void __launch_bounds__(256) k_dump_gather(const uint32_t* __restrict__ dump_iter, const float4* __restrict__ rec, uint32_t N,
-                                                      uint32_t last_iter, uint32_t n_alive, uint32_t n_step, const uint32_t* __restrict__ block_off,
+                                                      const Ctl* __restrict__ fin_state, const uint32_t* __restrict__ block_off,
                                                       float* __restrict__ last_sigmas, float* __restrict__ last_rgbs, float ps, float pr, float pg,
                                                       float pb) {
     __shared__ uint32_t ws[4];
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (fin_state->iters == 0) return;   // no iteration ran: the caller takes nothing from the tensors
+    const uint32_t last_iter = fin_state->iters - 1, n_alive = fin_state->last_n_alive, n_step = fin_state->last_n_step;
     const bool f = n < N && dump_iter[n] == last_iter;
     const unsigned long long bal = __ballot(f);
     if (lane == 0) ws[wid] = (uint32_t)__popcll(bal);
@@ -994,8 +996,8 @@ struct ngp_render_ctx {
     unsigned long long* stat_shards = nullptr;
     QueueHeads* heads = nullptr;  // device [2]
     _Float16* packed = nullptr;  // device
-    Ctl* status = nullptr;       // pinned, coherent [kRing]: written by k_render_compact, polled by the host
-    Ctl* status_dev = nullptr;   // the same ring as the device addresses it
+    unsigned long long* status = nullptr;       // pinned, coherent [kRing] status words: written by k_render_compact, polled by the host
+    unsigned long long* status_dev = nullptr;   // the same ring as the device addresses it
     uint32_t seq_base = 0;       // sequence numbers already used by earlier render calls (slots are matched by number)
     hipEvent_t ev[kRing];
     int num_cu = 256;
@@ -1053,9 +1055,9 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
     ok &= hipMalloc(&c->heads, 2 * sizeof(QueueHeads)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
-    ok &= hipHostMalloc(&c->status, kRing * sizeof(Ctl), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    ok &= hipHostMalloc(&c->status, kRing * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
     if (ok) {
-        memset(c->status, 0, kRing * sizeof(Ctl));
+        memset(c->status, 0, kRing * sizeof(unsigned long long));
         ok &= hipHostGetDevicePointer((void**)&c->status_dev, c->status, 0) == hipSuccess;
     }
     for (int i = 0; i < kRing; i++) ok &= hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
@@ -1178,7 +1180,6 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     uint32_t known = 0;       // iterations whose resulting status the host has read
     uint32_t launches = 2;
     bool done = false;
-    Ctl last = {};
     while (!done) {
         const uint32_t cur = launched & 1;
         const uint32_t chunks = div_up(ub ? ub : 1, 64);
@@ -1203,19 +1204,20 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         // consume every status that has already landed; block only when too far ahead
         while (known < launched) {
             const bool must_wait = launched - known >= (uint32_t)kLookahead;
-            volatile Ctl* slot = ctx->status + known % kRing;
+            volatile unsigned long long* slot = ctx->status + known % kRing;
             const uint32_t want_seq = ctx->seq_base + known + 1;
-            if (slot->pad != want_seq) {
+            unsigned long long w = *slot;
+            if ((uint32_t)(w >> 32) != want_seq) {
                 if (!must_wait) break;
                 uint32_t spins = 0;
-                while (slot->pad != want_seq) {
+                while ((uint32_t)((w = *slot) >> 32) != want_seq) {
                     if ((++spins & 0xFFFu) == 0) {   // every few thousand polls make sure the stream is still alive
                         const hipError_t q = hipStreamQuery(s);
                         if (q != hipSuccess && q != hipErrorNotReady) {
                             set_error("render_rays: %s", hipGetErrorString(q));
                             return NGP_ELAUNCH;
                         }
-                        if (q == hipSuccess && slot->pad != want_seq) {   // everything ran, nothing was published: cannot happen
+                        if (q == hipSuccess && (uint32_t)(*slot >> 32) != want_seq) {   // everything ran, nothing was published: cannot happen
                             set_error("render_rays: the device finished without publishing iteration %u", known);
                             return NGP_ELAUNCH;
                         }
@@ -1223,11 +1225,9 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
                     __builtin_ia32_pause();
                 }
             }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            last = *const_cast<Ctl*>(slot);
             known++;
-            ub = last.n_alive;
-            if (last.done) { done = true; break; }
+            ub = (uint32_t)w & 0x7FFFFFFFu;
+            if ((w >> 31) & 1ull) { done = true; break; }
         }
         if (launched > max_steps + 8u) {  // cannot happen: every iteration advances step by >= 1
             set_error("render_rays: iteration bound exceeded");
@@ -1235,11 +1235,12 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         }
     }
     ctx->seq_base += launched;
-    if (ra.dump_rec && last.iters > 0) {
+    if (ra.dump_rec) {
         const uint32_t nb = div_up(N, 256);
-        k_dump_count<<<nb, 256, 0, s>>>(ctx->dump_iter, N, last.iters - 1, ctx->chunk_count);
+        const Ctl* fin_state = ctx->ctl + (launched & 1);   // the state after the last launch (done is sticky)
+        k_dump_count<<<nb, 256, 0, s>>>(ctx->dump_iter, N, fin_state, ctx->chunk_count);
         k_dump_scan<<<1, 1024, 0, s>>>(ctx->chunk_count, nb);
-        k_dump_gather<<<nb, 256, 0, s>>>(ctx->dump_iter, ctx->dump_rec, N, last.iters - 1, last.last_n_alive, last.last_n_step, ctx->chunk_count,
+        k_dump_gather<<<nb, 256, 0, s>>>(ctx->dump_iter, ctx->dump_rec, N, fin_state, ctx->chunk_count,
                                          last_sigmas, last_rgbs, ra.pad_sigma, ra.pad_r, ra.pad_g, ra.pad_b);
     }
     rc = check_launch("render_rays");
@@ -1250,7 +1251,11 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             return NGP_ELAUNCH;
         }
         if (stats_host) {
-            const Ctl fin = ctx->status[(launched - 1) % kRing];  // state after the last enqueued iteration (done is sticky)
+            Ctl fin;   // state after the last enqueued iteration (done is sticky)
+            if (hipMemcpy(&fin, ctx->ctl + (launched & 1), sizeof(Ctl), hipMemcpyDeviceToHost) != hipSuccess) {
+                set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
+                return NGP_ELAUNCH;
+            }
             stats_host->samples_marched = fin.samples_marched;
             stats_host->samples_slots = fin.samples_slots;
             stats_host->iterations = fin.iters;
