@@ -267,6 +267,14 @@ NGP_API size_t ngp_uq_stats_workspace(void);
 NGP_API int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n, const float* r, uint64_t m, double* stats,
                  void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
+/* ---------------- optimiser step of Trainer.train_step (nerf/utils.py:404-487; main_nerf.py:116) ---------------- */
+
+/* torch.optim.Adam(betas, eps) without weight decay / amsgrad on one fp32 tensor, in place: exp_avg and exp_avg_sq are the
+ * optimiser state, `step` counts from 1 (bias corrections 1 - beta^step), the gradient is divided by grad_scale first
+ * (GradScaler.unscale_; pass 1).  One streaming pass, 28 B per parameter. */
+NGP_API int ngp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                  float beta2, float eps, uint32_t step, float grad_scale, ngp_stream_t stream);
+
 /* Diagnostics: when a device buffer of >= 16 uint64 is set, k_render_iter adds per-phase wave-cycle sums
  * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier; [4..6] march lane statistics; [8] encode + sigma net, [9] colour net, [10] tiles, [11] samples in them).  NULL (default) = no
  * stamp instruction executes. */

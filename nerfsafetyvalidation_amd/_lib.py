@@ -69,6 +69,7 @@ SIGNATURES = {
     "ngp_get_rays_backward": [_vp, _vp, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _u32, _vp, _vp],
     "ngp_uq_stats_workspace": [],
     "ngp_uq_stats": [_vp, _int, _vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _sz, _vp],
+    "ngp_adam_step": [_vp, _vp, _vp, _vp, C.c_uint64, _f32, _f32, _f32, _f32, _u32, _f32, _vp],
     "ngp_render_ctx_create": [_u32, C.POINTER(_vp)],
     "ngp_render_ctx_destroy": [_vp],
     "ngp_render_rays": [_vp, C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,

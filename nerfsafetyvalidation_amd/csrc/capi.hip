@@ -1,4 +1,5 @@
 // capi.hip -- error plumbing, version and the optional per-kernel event timing of libngp_hip.
+#include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -137,6 +138,44 @@ __global__ void k_uq_final(const double* __restrict__ partial, uint32_t blocks, 
     }
 }
 
+// ---- Adam (torch.optim.Adam as main_nerf.py:116 configures it: no weight decay, no amsgrad) -------------------
+// One streaming pass: 16 B read + 12 B written per parameter.  Same operation order as torch's single-tensor path:
+//   m = lerp(m, g, 1 - b1);  v = b2 * v + (1 - b2) * g * g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, uint64_t n, float beta1, float beta2, float eps, float step_size,
+                                                   float rsqrt_bc2_inv, float grad_scale_inv) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    const bool vec = i0 + 4 <= n && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    float pv[4], gv[4], mv[4], vv[4];
+    const uint32_t cnt = (uint32_t)(n - i0 < 4 ? n - i0 : 4);
+    if (vec) {
+        *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
+        *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i0);
+        *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i0);
+        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i0);
+    } else {
+        for (uint32_t k = 0; k < cnt; k++) { pv[k] = p[i0 + k]; gv[k] = g[i0 + k]; mv[k] = m[i0 + k]; vv[k] = v[i0 + k]; }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k < cnt) {
+            const float gr = gv[k] * grad_scale_inv;
+            mv[k] = mv[k] + (1.0f - beta1) * (gr - mv[k]);                 // torch lerp_: start + weight * (end - start) for weight < 0.5
+            vv[k] = beta2 * vv[k] + (1.0f - beta2) * gr * gr;             // mul_(beta2).addcmul_(g, g, value = 1 - beta2)
+            const float denom = sqrtf(vv[k]) / rsqrt_bc2_inv + eps;       // (v.sqrt() / sqrt(bias_correction2)).add_(eps)
+            pv[k] = pv[k] - step_size * (mv[k] / denom);                  // addcdiv_(m, denom, value = -step_size)
+        }
+    }
+    if (vec) {
+        *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<float4*>(pv);
+        *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<float4*>(mv);
+        *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<float4*>(vv);
+    } else {
+        for (uint32_t k = 0; k < cnt; k++) { p[i0 + k] = pv[k]; m[i0 + k] = mv[k]; v[i0 + k] = vv[k]; }
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -174,6 +213,22 @@ int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n, const f
     if (rc) return rc;
     k_uq_final<<<1, 64, 0, s>>>((const double*)workspace, blocks, n, m, stats);
     return check_launch("uq_stats (final)");
+}
+
+int ngp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1, float beta2, float eps,
+                  uint32_t step, float grad_scale, ngp_stream_t stream) {
+    if (n == 0) return NGP_OK;
+    NGP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam_step: null pointer");
+    NGP_REQUIRE(step >= 1, "adam_step: step counts from 1");
+    NGP_REQUIRE(grad_scale != 0.0f, "adam_step: grad_scale must be non-zero");
+    // bias corrections in double, rounded like torch's Python floats handed to the kernels
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float sqrt_bc2 = (float)sqrt(bc2);
+    const uint64_t quads = (n + 3) / 4;
+    k_adam_step<<<(uint32_t)((quads + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size,
+                                                                                   sqrt_bc2, 1.0f / grad_scale);
+    return check_launch("adam_step");
 }
 
 int ngp_prof_enable(int on) {

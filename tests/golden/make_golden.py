@@ -279,13 +279,24 @@ def gen_train_step():
     target = torch.rand(1, 24, 3, generator=g)
     out = net.render(ro, rd, staged=False, bg_color=1, perturb=True, force_all_rays=True, dt_gamma=0, max_steps=1024)
     loss = ((out["image"] - target) ** 2).mean()
+    before = {k: v.copy() for k, v in _weights(net).items()}
     loss.backward()
     emb_g = net.encoder.embeddings.grad
     nz = emb_g.abs().sum(-1).nonzero().squeeze(-1)
+    grads = {f"g_{k}": v.copy() for k, v in _grads(net).items()}
+    emb_vals = emb_g[nz].numpy().copy()
+    # the optimiser step of Trainer.train_step with the optimiser main_nerf.py:116 builds (two steps on the same gradients:
+    # exercises the bias corrections and non-zero moments)
+    opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    opt.step()
+    opt.step()
+    after = {f"after_{k}": v for k, v in _weights(net).items()}
+    after["after_emb_rows"] = net.encoder.embeddings.detach()[nz].numpy().copy()
+    save("train_adam.npz", lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, steps=2, **after)
     save("train_step.npz", bound=bound, H=H, W=W, view=91, density_scale=48.0, table_seed=0, inds=inds.numpy(), target=target.numpy(),
          bitfield_sha256=SC.bitfield_sha256(sc.bitfield()), image=out["image"].detach().numpy(), depth=out["depth"].detach().numpy(),
          weights_sum=out["weights_sum"].detach().numpy(), loss=float(loss), emb_grad_rows=nz.numpy().astype(np.int32),
-         emb_grad_vals=emb_g[nz].numpy(), **{f"g_{k}": v for k, v in _grads(net).items()}, **_weights(net))
+         emb_grad_vals=emb_vals, **grads, **before)
 
 
 def gen_uq():

@@ -179,6 +179,53 @@ def test_train_step_golden(device):
     assert abs(float(loss.detach()) - float(f["loss"])) < 1e-5
     loss.backward()
     _check_param_grads(net, f, rtol=2e-3, atol_scale=2e-4)
+    # ... and the optimiser step: two steps of the HIP Adam on those gradients against torch.optim.Adam as main_nerf.py:116
+    # configures it (train_adam.npz).  Moved parameters agree to the gradients' own accuracy; untouched table rows do not move.
+    from nerfsafetyvalidation_amd.optim import Adam
+    a = load("train_adam.npz")
+    before_emb = net.encoder.embeddings.detach().clone()
+    opt = Adam(net.get_params(float(a["lr"])), betas=(float(a["beta1"]), float(a["beta2"])), eps=float(a["eps"]))
+    for _ in range(int(a["steps"])):
+        opt.step()
+    rows = f["emb_grad_rows"]
+    moved = net.encoder.embeddings.detach()
+    lr = float(a["lr"])
+    np.testing.assert_allclose(moved[rows].cpu().numpy(), a["after_emb_rows"], rtol=0, atol=4 * lr)   # Adam moves an entry by <= ~lr per step whatever |g|
+    agree = np.isclose(moved[rows].cpu().numpy(), a["after_emb_rows"], rtol=0, atol=1e-3 * lr).mean()
+    assert agree > 0.99, agree             # entries whose tiny gradient differs in the last bits (float atomics order) move differently
+    mask = torch.ones(moved.shape[0], dtype=torch.bool, device=device)
+    mask[torch.from_numpy(rows).to(device).long()] = False
+    assert torch.equal(moved[mask], before_emb[mask])
+    for name, layers in (("sigma", net.sigma_net), ("color", net.color_net)):
+        for i, l in enumerate(layers):
+            w_ = l.weight.detach().cpu().numpy()
+            np.testing.assert_allclose(w_, a[f"after_{name}{i}"], rtol=0, atol=4 * lr)
+            assert np.isclose(w_, a[f"after_{name}{i}"], rtol=0, atol=1e-3 * lr).mean() > 0.99
+    assert set(opt.state_dict()["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}          # torch.optim.Adam's state layout
+
+
+def test_adam_step_matches_torch(device):
+    """ngp_adam_step against torch.optim.Adam on the same device, several steps, odd sizes, loss-scaled gradients"""
+    from nerfsafetyvalidation_amd.optim import Adam
+    torch.manual_seed(0)
+    for n in (1, 7, 4096, 100003):
+        p0 = torch.randn(n, device=device)
+        pa, pb = p0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+        oa = torch.optim.Adam([pa], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, foreach=False, fused=False)
+        ob = Adam([pb], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+        for step in range(5):
+            g = torch.randn(n, device=device) * (10.0 ** (step - 2))
+            pa.grad = g.clone()
+            pb.grad = g.clone() * 128.0
+            oa.step()
+            ob.step(grad_scale=128.0)
+        np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=2e-6, atol=2e-6)
+        sa, sb = oa.state[pa], ob.state[pb]
+        # moments are running sums of terms 10^-2 .. 10^2 apart: compare relative to their scale
+        ea, eb = sa["exp_avg"].cpu().numpy(), sb["exp_avg"].cpu().numpy()
+        np.testing.assert_allclose(eb, ea, rtol=2e-6, atol=1e-6 * np.abs(ea).max())
+        va, vb = sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].cpu().numpy()
+        np.testing.assert_allclose(vb, va, rtol=2e-6, atol=1e-6 * np.abs(va).max())
 
 
 def test_uq_gaussian_golden(device):
