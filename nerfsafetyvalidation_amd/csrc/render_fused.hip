@@ -6,12 +6,13 @@
 // for the boolean-mask compaction) becomes two launches and no host round trip:
 //
 //   k_render_iter   512-thread workgroups (8 waves).  A wave owns 64 alive rays:
-//     1. lane = ray: occupancy-grid DDA (ngp::Dda, bit-identical to march_rays) emits up to
-//        n_step sample parameters (t, dt) into the wave's LDS slab -- no [M,3] xyzs/dirs/deltas;
+//     1. lane = ray: occupancy-grid DDA (ngp::Dda; same sample sequence as march_rays, reached with the exact
+//        shortcuts of Dda::probe_lin / skip_const_dt / jump_block) emits up to kCh sample parameters (t, dt)
+//        per sub-pass into the wave's LDS slab -- no [M,3] xyzs/dirs/deltas;
 //     2. the wave's valid samples are compacted (wave prefix sum) and processed 16 at a time:
 //        lane = (sample c = lane & 15, quarter q = lane >> 4).  Each lane gathers 4 of the 16
 //        hash levels (q, q+4, q+8, q+12; 32 four-byte table reads in flight per lane) and
-//        interpolates them with the reference's fp16 rounding sequence.  Its 8 features ARE the
+//        interpolates them (fp32 accumulation, one rounding to fp16).  Its 8 features ARE the
 //        B fragment of v_mfma_f32_16x16x32_f16 for the TRANSPOSED product H^T = W * X^T, so
 //        the encoder output never touches memory.  Every following layer consumes the previous
 //        accumulator directly as its B fragment (the k-order permutation this implies is folded
@@ -19,15 +20,16 @@
 //        Weights live in LDS as ready-made A fragments (16 B per lane, conflict-free b128 reads).
 //     3. lane = ray again: composite_rays arithmetic on the wave's LDS results, state update,
 //        survivor ballot -> block-local stable compaction into a staging list.
-//   k_render_compact  stitches the per-group survivor lists into the next alive list (stable,
-//        = rays_alive[rays_alive >= 0]) and evaluates the reference's schedule on the device:
+//   k_render_compact  stitches the per-group survivor lists into the next alive list (stable; rays whose next
+//        march starts in empty space first) and evaluates the reference's schedule on the device:
 //        n_step = clamp(N // n_alive, 1, 8), step += n_step, stop when step >= max_steps.
 //
 // The host enqueues iterations ahead of the device-side state (kernels read n_alive / n_step from
 // device memory and return immediately once `done` is set) and learns the state through a pinned
 // status ring, so the stream never drains while the host catches up.
 //
-// Numerics: identical expressions to the operator kernels (explicit fmaf, -ffp-contract=off).
+// Numerics: the operator kernels' expressions (explicit fmaf, -ffp-contract=off) except the fp32 corner accumulation
+// noted above; DESIGN.md section 5.
 #include <hip/hip_fp16.h>
 #include <math.h>
 #include <string.h>
