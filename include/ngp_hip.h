@@ -214,7 +214,7 @@ typedef struct ngp_render_stats {
     uint32_t last_n_alive;        /* n_alive and n_step of the last iteration             */
     uint32_t last_n_step;
     uint32_t launches;            /* kernel launches enqueued (incl. run-ahead no-ops)    */
-    uint32_t reserved;
+    uint32_t replayed;            /* 1: a multi-iteration launch failed its verification and the call was rendered again, one reference iteration per launch */
 } ngp_render_stats;
 
 typedef struct ngp_render_ctx ngp_render_ctx;  /* pinned status ring, events, scratch sizes */
@@ -282,7 +282,7 @@ NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
 /* Diagnostics: uint32[N] device buffer receiving, per ray, an FNV-1a hash over the bit patterns of (dt, deltas[1]) of every
  * sample the fused renderer marched, in order (NULL = off).  Lets a test prove the fused path's sample sequence equal to
  * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 0 / bit 1 disable the coarse occupancy filter, bit 2 the
- * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
+ * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
 

@@ -143,7 +143,8 @@ class FusedModel:
         sigmas = rgbs = None
         if need_stats:
             self.last_stats = {"samples_marched": int(stats.samples_marched), "samples_slots": int(stats.samples_slots),
-                               "iterations": int(stats.iterations), "rays": int(stats.rays), "launches": int(stats.launches)}
+                               "iterations": int(stats.iterations), "rays": int(stats.rays), "launches": int(stats.launches),
+                               "replayed": int(stats.replayed)}
         if want_last and stats.iterations > 0:
             M = stats.last_n_alive * stats.last_n_step
             M += 128 - (M % 128)  # F11

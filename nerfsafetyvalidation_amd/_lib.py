@@ -33,7 +33,7 @@ class ModelStruct(C.Structure):
 class RenderStats(C.Structure):
     """struct ngp_render_stats"""
     _fields_ = [("samples_marched", C.c_uint64), ("samples_slots", C.c_uint64), ("iterations", _u32), ("rays", _u32),
-                ("last_n_alive", _u32), ("last_n_step", _u32), ("launches", _u32), ("reserved", _u32)]
+                ("last_n_alive", _u32), ("last_n_step", _u32), ("launches", _u32), ("replayed", _u32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES).  Mirrors include/ngp_hip.h one to one;

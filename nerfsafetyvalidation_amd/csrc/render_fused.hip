@@ -57,7 +57,21 @@ struct Ctl {
     uint32_t n_alive, n_step, step, done;
     uint32_t iters, last_n_alive, last_n_step, pad;
     unsigned long long samples_marched, samples_slots;
+    uint32_t spec, violated, rsv[2];   // see "several reference iterations per launch" below
 };
+
+// Several reference iterations per launch.  While more than half of the N rays are alive the reference's schedule is
+// n_step = clamp(N // n_alive, 1, 8) = 1: one sample per ray and iteration, for dozens of iterations (50 of the 56 of an 800x800
+// Stonehenge frame), each paying a launch, the per-ray state round trip and a compaction for a single sample.  A launch with
+// `spec` set covers K = n_step consecutive reference iterations of one sample each: per ray it emulates the iteration
+// boundaries exactly (march restarts from the re-accumulated rays_t, raymarching.cu:727,848) and the per-iteration death
+// counts give the n_alive sequence, so iterations / samples_slots / step are the reference's.  That is valid only if n_alive
+// stays above N/2 through the K iterations; it is entered with a margin (kSpecMargin) and VERIFIED afterwards: a violation
+// sets `violated` and ngp_render_rays renders the call again without it.  Not used with perturb (the jitter of an iteration
+// is seeded with the ray's index in that iteration's list).
+constexpr uint32_t kSpecK = 8;            // reference iterations per speculative launch
+constexpr uint32_t kSpecMarginDiv = 16;   // entered only while n_alive - N/2 > N / kSpecMarginDiv
+constexpr int kDeathShards = 64;
 // work-queue heads: one per shard (chunk c belongs to shard c & 7), each on its own 128-byte line, two sets (ping-pong with Ctl)
 struct QueueHeads { uint32_t head[8][32]; };
 
@@ -513,6 +527,7 @@ struct RenderArgs {
     Ctl* ctl;                         // state read by this iteration
     QueueHeads* heads;                // its work-queue heads (zeroed by the previous k_render_compact / k_render_init)
     unsigned long long* stat_shards;  // [kStatShards] marched-sample counters (summed by k_render_compact)
+    uint32_t* death_shards;           // [kDeathShards][kSpecK] rays that died in the k-th iteration of a speculative launch
     const uint8_t* bitfield;
     uint32_t cascade, grid_size, max_steps, perturb;
     float dt_gamma;
@@ -552,6 +567,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
     const uint32_t n_alive = ctl.n_alive, n_step = ctl.n_step;
+    const bool spec = ctl.spec != 0;   // n_step reference iterations of ONE sample each (see Ctl)
     const uint32_t n_chunks = (n_alive + 63) / 64;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -617,7 +633,9 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             S.od[lane][0] = dda.ox; S.od[lane][1] = dda.oy; S.od[lane][2] = dda.oz;
             S.od[lane][3] = dda.dx; S.od[lane][4] = dda.dy; S.od[lane][5] = dda.dz;
         }
-        float last_m = last_t;               // march-side copy of last_t (sample-hash diagnostics)
+        float last_m = last_t;               // march-side copy of last_t
+        float geo_tc = t_c;                  // march-side copy of rays_t across the iteration boundaries of a speculative launch
+        uint32_t ref_marched = 0;            // speculative launches: samples the reference's iterations march for this ray
         uint32_t hsh = 0;
         if (active && ra.sample_hash) hsh = ra.sample_hash[ray];
         // ray states: running -> (terminated by T < 1e-4 | exhausted: the march ran out of samples) -> dead
@@ -639,11 +657,18 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                         S.t[lane * kCh + cnt] = t_march;
                         S.dt[lane * kCh + cnt] = dt;
                         t_march += dt;
+                        const float d1 = t_march - last_m;   // deltas[1] of this sample (:791-793)
+                        last_m = t_march;
                         if (ra.sample_hash) {
-                            const float d1 = t_march - last_m;
-                            last_m = t_march;
                             hsh = (hsh ^ __float_as_uint(dt)) * 16777619u;
                             hsh = (hsh ^ __float_as_uint(d1)) * 16777619u;
+                        }
+                        if (spec) {
+                            // iteration boundary: composite_rays leaves rays_t = t + deltas[1] (:848) and the next march_rays starts
+                            // from it with last_t = t (:727-731)
+                            geo_tc += d1;
+                            t_march = geo_tc;
+                            last_m = geo_tc;
                         }
                         cnt++;
                     }
@@ -723,6 +748,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     const float t_after = S.t[slot] + dt;
                     const float delta1 = t_after - last_t;   // deltas[1] as march_rays wrote it (:791-793)
                     last_t = t_after;
+                    ref_marched++;
                     const float sg = S.sig[slot];
                     const uint32_t rg = S.rg[slot];
                     const float sr = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg & 0xffffu));
@@ -735,6 +761,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     t_c += delta1;
                     dep = fmaf(w, t_c, dep);
                     cr = fmaf(w, sr, cr); cg = fmaf(w, sgc, cg); cb = fmaf(w, sb, cb);
+                    if (spec) last_t = t_c;                  // the next iteration's march_rays restarts its delta chain from rays_t
                     if ((double)T < 1e-4) break;             // :890: this sample does not count as a completed step
                 }
                 steps_done += k;
@@ -778,6 +805,20 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         if (survive && !slow) ra.staging[(size_t)chunk * 64 + (uint32_t)__popcll(ball_f & lt_mask)] = ray;
         if (survive && slow) ra.staging[(size_t)chunk * 64 + 63 - (uint32_t)__popcll(ball_s & lt_mask)] = ray;   // filled from the back
         if (lane == 0) ra.chunk_count[chunk] = (uint32_t)__popcll(ball_f) | ((uint32_t)__popcll(ball_s) << 16);
+        if (spec) {
+            // a ray that completed m samples died in the launch's m-th iteration: the n_alive sequence follows from these counts.
+            // The samples the reference marches are those of the iterations the ray entered alive (march-ahead within a sub-pass
+            // may have produced one more).
+            const uint32_t ds = ((blockIdx.x * kWaves + wid) % kDeathShards) * kSpecK;
+            for (uint32_t m = 0; m < n_step; m++) {
+                const uint32_t cdead = (uint32_t)__popcll(__ballot(active && !survive && steps_done == m));
+                if (lane == 0 && cdead) atomicAdd(&ra.death_shards[ds + m], cdead);
+            }
+            uint32_t rm = ref_marched;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) rm += __shfl_xor(rm, off, 64);
+            wave_samples = rm;
+        }
         wave_total += wave_samples;
         // padding rows of the reference's [M_padded] tensors (M += 128 - M % 128), written by the last chunk's wave
         if (ra.dump_iter && active) ra.dump_iter[ray] = ctl.iters;
@@ -812,7 +853,8 @@ __device__ __forceinline__ void publish_status(unsigned long long* host_slot, co
 __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ cur, Ctl* __restrict__ nxt, const int32_t* __restrict__ staging,
                                                          const uint32_t* __restrict__ chunk_count, int32_t* __restrict__ alive_out, uint32_t N,
                                                          uint32_t max_steps, const unsigned long long* __restrict__ stat_shards,
-                                                         QueueHeads* __restrict__ nxt_heads, unsigned long long* __restrict__ host_slot, uint32_t seq) {
+                                                         QueueHeads* __restrict__ nxt_heads, unsigned long long* __restrict__ host_slot, uint32_t seq,
+                                                         uint32_t* __restrict__ death_shards, uint32_t spec_allowed) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
     const Ctl c = *cur;
@@ -866,18 +908,58 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
     unsigned long long marched = threadIdx.x < (uint32_t)kStatShards ? stat_shards[threadIdx.x] : 0ull;   // kStatShards == 64: wave 0
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) marched += __shfl_down(marched, off, 64);
+    // deaths per iteration of a speculative launch (wave 1 sums the shards; every block does, only the last one uses them)
+    __shared__ uint32_t deaths[kSpecK];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kSpecK) {
+        uint32_t d = 0;
+        if (c.spec)
+            for (int sh = 0; sh < kDeathShards; sh++) d += death_shards[sh * kSpecK + (threadIdx.x - 64)];
+        deaths[threadIdx.x - 64] = d;
+    }
+    __syncthreads();
     if (g == n_blocks - 1 && threadIdx.x == 0) {
         Ctl n = c;
         n.samples_marched = marched;
-        n.last_n_alive = c.n_alive;
-        n.last_n_step = c.n_step;
-        n.iters = c.iters + 1;
-        n.samples_slots = c.samples_slots + (unsigned long long)c.n_alive * c.n_step;
-        n.step = c.step + c.n_step;
         n.n_alive = total_s + prefix_f + off_f[8];
+        if (!c.spec) {
+            n.last_n_alive = c.n_alive;
+            n.last_n_step = c.n_step;
+            n.iters = c.iters + 1;
+            n.samples_slots = c.samples_slots + (unsigned long long)c.n_alive * c.n_step;
+            n.step = c.step + c.n_step;
+        } else {
+            // K = c.n_step reference iterations of one sample each: n_alive(i + j) = n_alive(i) - deaths before j.  Each must have
+            // been run with n_step = clamp(N // n_alive, 1, 8) == 1, i.e. n_alive > N / 2; the loop would also have stopped at the
+            // first empty list.
+            uint32_t alive = c.n_alive, it = 0;
+            unsigned long long slots = c.samples_slots;
+            bool bad = false;
+            for (uint32_t j = 0; j < c.n_step; j++) {
+                if (alive == 0) { bad = true; break; }            // the reference stops here; this launch ran on
+                if (j > 0 && (N / alive) != 1) bad = true;        // that iteration should have marched more than one sample
+                slots += alive;
+                it++;
+                n.last_n_alive = alive;
+                n.last_n_step = 1;
+                alive -= deaths[j];
+            }
+            if (alive != n.n_alive) bad = true;                   // bookkeeping must close: survivors == alive after the last iteration
+            n.iters = c.iters + it;
+            n.samples_slots = slots;
+            n.step = c.step + c.n_step;
+            if (bad) n.violated = 1;
+            for (int i = threadIdx.x; i < kDeathShards * (int)kSpecK; i++) death_shards[i] = 0;   // (one thread: 512 words, once per launch)
+        }
         uint32_t ns = n.n_alive ? N / n.n_alive : 8;
         n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
         n.done = (n.n_alive == 0 || n.step >= max_steps) ? 1 : 0;
+        // the next launch may cover several reference iterations: schedule in the n_step = 1 regime with room to spare
+        n.spec = 0;
+        if (spec_allowed && !n.done && !n.violated && n.n_step == 1 && n.n_alive > N / 2 + N / kSpecMarginDiv) {
+            const uint32_t room = max_steps - n.step;
+            const uint32_t K = room < kSpecK ? room : kSpecK;
+            if (K >= 2) { n.spec = 1; n.n_step = K; }
+        }
         *nxt = n;
         for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
         publish_status(host_slot, n, seq);
@@ -888,9 +970,10 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
                                                       int32_t* __restrict__ alive, float* __restrict__ weights_sum, float* __restrict__ depth,
                                                       float* __restrict__ image, Ctl* __restrict__ ctl, uint32_t max_steps,
                                                       uint32_t* __restrict__ sample_hash, unsigned long long* __restrict__ stat_shards,
-                                                      QueueHeads* __restrict__ heads) {
+                                                      QueueHeads* __restrict__ heads, uint32_t* __restrict__ death_shards, uint32_t spec_allowed) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n < (uint32_t)kStatShards) stat_shards[n] = 0ull;
+    if (n < (uint32_t)kDeathShards * kSpecK) death_shards[n] = 0;
     if (n < 16) heads[n >> 3].head[n & 7][0] = 0;
     if (n < N) {
         if (sample_hash) sample_hash[n] = 2166136261u;
@@ -904,6 +987,10 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
         c.n_alive = N;
         c.n_step = 1;  // clamp(N // N, 1, 8)
         c.done = (N == 0 || max_steps == 0) ? 1 : 0;
+        if (spec_allowed && !c.done && N > N / 2 + N / kSpecMarginDiv && max_steps >= 2) {   // see Ctl: several iterations per launch
+            c.spec = 1;
+            c.n_step = max_steps < kSpecK ? max_steps : kSpecK;
+        }
         ctl[0] = c;
         ctl[1] = c;
     }
@@ -992,6 +1079,8 @@ struct ngp_render_ctx {
     float* rays_t = nullptr;
     unsigned long long* coarse = nullptr;   // coarse occupancy bits (<= 8 KB)
     uint32_t* grid_lin = nullptr;           // x-fastest copy of the occupancy bitfield (k_build_linear), allocated on first use
+    uint32_t* death_shards = nullptr;       // [kDeathShards][kSpecK] per-iteration death counts of a speculative launch
+    bool no_spec = false;                   // set for the replay of a call whose speculation was violated
     float4* dump_rec = nullptr;             // lazily allocated: [max_rays][8]
     uint32_t* dump_iter = nullptr;          // [max_rays]
     Ctl* ctl = nullptr;          // device [2]
@@ -1010,6 +1099,7 @@ static uint32_t* g_sample_hash = nullptr;
 static bool g_coarse_off = false;
 static bool g_lin_off = false;
 static bool g_jump_off = false;
+static bool g_spec_off = false;
 static bool g_sort_off = false;
 
 static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
@@ -1055,6 +1145,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->coarse, kCoarseMaxBytes) == hipSuccess;
     ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
     ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
+    ok &= hipMalloc(&c->death_shards, (size_t)kDeathShards * kSpecK * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&c->heads, 2 * sizeof(QueueHeads)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
     ok &= hipHostMalloc(&c->status, kRing * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -1078,7 +1169,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
-    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
+    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->death_shards); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -1107,8 +1198,10 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
     k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
                                                          (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
+    // several reference iterations per launch (see Ctl): needs the end-of-call state on the host to verify it, no jitter
+    const uint32_t spec_allowed = (!g_spec_off && !ctx->no_spec && perturb == 0 && (sync || stats_host)) ? 1u : 0u;
     k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
-                                                 g_sample_hash, ctx->stat_shards, ctx->heads);
+                                                 g_sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed);
 
     RenderArgs ra = {};
     ra.rays_o = rays_o; ra.rays_d = rays_d; ra.fars = fars; ra.rays_t = ctx->rays_t;
@@ -1116,6 +1209,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     ra.last_sigmas = last_sigmas; ra.last_rgbs = last_rgbs;
     if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
     ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count; ra.stat_shards = ctx->stat_shards;
+    ra.death_shards = ctx->death_shards;
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
@@ -1200,7 +1294,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
-                                                           ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1);
+                                                           ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1, ctx->death_shards,
+                                                           spec_allowed);
         launched++;
         launches += 2;
         // consume every status that has already landed; block only when too far ahead
@@ -1252,12 +1347,26 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
             return NGP_ELAUNCH;
         }
-        if (stats_host) {
-            Ctl fin;   // state after the last enqueued iteration (done is sticky)
-            if (hipMemcpy(&fin, ctx->ctl + (launched & 1), sizeof(Ctl), hipMemcpyDeviceToHost) != hipSuccess) {
-                set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
+        Ctl fin;   // state after the last enqueued iteration (done is sticky)
+        if (hipMemcpy(&fin, ctx->ctl + (launched & 1), sizeof(Ctl), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
+            return NGP_ELAUNCH;
+        }
+        if (fin.violated) {
+            // a launch that covered several reference iterations turned out not to be equivalent to them (more than the margin
+            // of rays died inside it): render the call again, one reference iteration per launch
+            if (ctx->no_spec) {
+                set_error("render_rays: schedule verification failed without speculation (internal error)");
                 return NGP_ELAUNCH;
             }
+            ctx->no_spec = true;
+            const int rc2 = ngp_render_rays(ctx, model, rays_o, rays_d, nears, fars, N, dt_gamma, max_steps, perturb, weights_sum, depth, image,
+                                            last_sigmas, last_rgbs, pad_value_host, stats_host, sync, stream);
+            ctx->no_spec = false;
+            if (stats_host && rc2 == NGP_OK) stats_host->replayed = 1;
+            return rc2;
+        }
+        if (stats_host) {
             stats_host->samples_marched = fin.samples_marched;
             stats_host->samples_slots = fin.samples_slots;
             stats_host->iterations = fin.iters;
@@ -1265,6 +1374,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             stats_host->last_n_alive = fin.last_n_alive;
             stats_host->last_n_step = fin.last_n_step;
             stats_host->launches = launches;
+            stats_host->replayed = 0;
             prof_add_units("k_render_iter", (double)fin.samples_marched);
         }
     }
@@ -1286,6 +1396,7 @@ int ngp_debug_disable_march_queue(int off) {
     g_sort_off = (off & 4) != 0;
     g_lin_off = (off & 8) != 0;
     g_jump_off = (off & 1) != 0;
+    g_spec_off = (off & 256) != 0;
     const uint32_t sh = (uint32_t)(off >> 4) & 15u;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(d_dbg_shrink), &sh, 4);
     return NGP_OK;

@@ -162,8 +162,9 @@ def test_fused_handles_edge_cases(setup, device):
 
 
 def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
-    """The fused DDA's shortcuts (x-fastest bit layout, one-step exit from empty 4x4x4 blocks) against its plain cell walk:
-    same network, so every ray's (dt, delta) sample sequence hash and the image must be IDENTICAL, not merely close."""
+    """The fused renderer's shortcuts (x-fastest bit layout, one-step exit from empty 4x4x4 blocks, several reference
+    iterations per launch) against its plain form: same network, so every ray's (dt, delta) sample sequence hash, the image
+    and the reference's schedule statistics must be IDENTICAL, not merely close."""
     from nerfsafetyvalidation_amd import _lib
     sc, model, _ = setup
     model.fused = True
@@ -172,7 +173,7 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
     N = ro.shape[0]
     outs = {}
     try:
-        for flags in (0, 1, 8):          # all shortcuts / no block jump / Morton-order probes (no linear layout, no jump)
+        for flags in (0, 1, 8, 256):     # all shortcuts / no block jump / Morton-order probes / one reference iteration per launch
             lib.ngp_debug_disable_march_queue(flags)
             h = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(h.data_ptr())
@@ -183,10 +184,12 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
     finally:
         lib.ngp_debug_set_sample_hash(None)
         lib.ngp_debug_disable_march_queue(0)
-    for flags in (1, 8):
+    for flags in (1, 8, 256):
         assert torch.equal(outs[0][0], outs[flags][0]), flags
         assert torch.equal(outs[0][1], outs[flags][1]), flags
-        assert outs[0][2]["samples_marched"] == outs[flags][2]["samples_marched"]
+        for key in ("samples_marched", "samples_slots", "iterations"):
+            assert outs[0][2][key] == outs[flags][2][key], (flags, key)
+    assert outs[0][2]["launches"] < outs[256][2]["launches"]      # several reference iterations per launch were used
     assert outs[0][2]["samples_marched"] > 10000
 
 
@@ -218,6 +221,33 @@ def test_fused_vs_operator_loop_across_configurations(device, bound, dt_gamma, p
     assert d.max().item() < 6e-3 and d.mean().item() < 3e-4, (d.max().item(), d.mean().item())
     dd = (da - db).abs()
     assert dd.max().item() < 2e-2 and dd.mean().item() < 5e-4, (dd.max().item(), dd.mean().item())
+
+
+def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
+    """A launch covering several reference iterations assumes n_alive stays above N/2.  With a density so high that most
+    rays saturate within a few samples the assumption fails inside the first launch: the device flags it, the call is
+    rendered again one iteration per launch, and the result equals the plain loop's bit for bit."""
+    from nerfsafetyvalidation_amd import _lib
+    sc, model, _ = setup
+    model.fused = True
+    lib = _lib.lib()
+    ro, rd = Hh.pinhole_rays(sc.poses[57], sc.intrinsics, sc.H, sc.W)
+    old_scale = model.density_scale
+    outs = {}
+    try:
+        model.density_scale = 4.0e4
+        for flags in (0, 256):
+            lib.ngp_debug_disable_march_queue(flags)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                img = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False)["image"].float()
+            outs[flags] = (img.clone(), dict(model.last_render_stats))
+    finally:
+        model.density_scale = old_scale
+        lib.ngp_debug_disable_march_queue(0)
+    assert outs[0][1]["replayed"] == 1 and outs[256][1]["replayed"] == 0
+    assert torch.equal(outs[0][0], outs[256][0])
+    for key in ("samples_marched", "samples_slots", "iterations"):
+        assert outs[0][1][key] == outs[256][1][key], key
 
 
 def test_linear_backbone_fused_vs_operator_loop(device):
