@@ -66,11 +66,16 @@ struct Ctl {
 // `spec` set covers K = n_step consecutive reference iterations of one sample each: per ray it emulates the iteration
 // boundaries exactly (march restarts from the re-accumulated rays_t, raymarching.cu:727,848) and the per-iteration death
 // counts give the n_alive sequence, so iterations / samples_slots / step are the reference's.  That is valid only if n_alive
-// stays above N/2 through the K iterations; it is entered with a margin (kSpecMargin) and VERIFIED afterwards: a violation
+// stays above N/2 through the K iterations; K is sized from the recent death rate with a factor 2 to spare and the
+// assumption is VERIFIED afterwards: a violation
 // sets `violated` and ngp_render_rays renders the call again without it.  Not used with perturb (the jitter of an iteration
 // is seeded with the ray's index in that iteration's list).
 constexpr uint32_t kSpecK = 8;            // reference iterations per speculative launch
-constexpr uint32_t kSpecMarginDiv = 16;   // entered only while n_alive - N/2 > N / kSpecMarginDiv
+constexpr uint32_t kSpecMarginDiv = 16;   // first launch: entered only if n_alive - N/2 > N / kSpecMarginDiv
+// q = 2 works the same way but is not entered: a frame's last iterations, where n_step has grown to 2, end in a mass
+// die-off (rays reach `far` together) that no recent rate predicts -- measured: a replay per frame for 50 us saved.
+constexpr uint32_t kSpecMaxQ = 1;
+constexpr uint32_t kSpecSafetyX2 = 4;     // later launches: sized for 2 x the recent death rate (kSpecSafetyX2 / 2)
 constexpr int kDeathShards = 64;
 // work-queue heads: one per shard (chunk c belongs to shard c & 7), each on its own 128-byte line, two sets (ping-pong with Ctl)
 struct QueueHeads { uint32_t head[8][32]; };
@@ -567,7 +572,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
     const uint32_t n_alive = ctl.n_alive, n_step = ctl.n_step;
-    const bool spec = ctl.spec != 0;   // n_step reference iterations of ONE sample each (see Ctl)
+    const uint32_t spec = ctl.spec;    // != 0: the launch covers n_step / spec reference iterations of `spec` samples each (see Ctl)
     const uint32_t n_chunks = (n_alive + 63) / 64;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -636,6 +641,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         float last_m = last_t;               // march-side copy of last_t
         float geo_tc = t_c;                  // march-side copy of rays_t across the iteration boundaries of a speculative launch
         uint32_t ref_marched = 0;            // speculative launches: samples the reference's iterations march for this ray
+        uint32_t emitted = 0;                // samples marched by this lane in this launch
         uint32_t hsh = 0;
         if (active && ra.sample_hash) hsh = ra.sample_hash[ray];
         // ray states: running -> (terminated by T < 1e-4 | exhausted: the march ran out of samples) -> dead
@@ -664,11 +670,13 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                             hsh = (hsh ^ __float_as_uint(d1)) * 16777619u;
                         }
                         if (spec) {
-                            // iteration boundary: composite_rays leaves rays_t = t + deltas[1] (:848) and the next march_rays starts
-                            // from it with last_t = t (:727-731)
+                            // composite_rays accumulates rays_t += deltas[1] per sample (:848); at an iteration boundary the next
+                            // march_rays starts from that value with last_t = t (:727-731)
                             geo_tc += d1;
-                            t_march = geo_tc;
-                            last_m = geo_tc;
+                            if (++emitted % spec == 0) {
+                                t_march = geo_tc;
+                                last_m = geo_tc;
+                            }
                         }
                         cnt++;
                     }
@@ -740,6 +748,12 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             }
             NGP_STAMP(1)
             // ---- 3. composite (raymarching.cu:860-897), lane = ray
+            if (running && spec) {
+                // samples the reference marches: every sample of an iteration the ray enters alive (march_rays runs before
+                // composite_rays).  spec == 2: the sub-pass is one iteration; spec == 1: it holds two, the second counts only if the
+                // first is survived (added below)
+                ref_marched += spec == 1 ? (cnt ? 1u : 0u) : cnt;
+            }
             if (running) {
                 uint32_t k = 0;
                 for (; k < cnt; k++) {
@@ -748,7 +762,6 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     const float t_after = S.t[slot] + dt;
                     const float delta1 = t_after - last_t;   // deltas[1] as march_rays wrote it (:791-793)
                     last_t = t_after;
-                    ref_marched++;
                     const float sg = S.sig[slot];
                     const uint32_t rg = S.rg[slot];
                     const float sr = (float)__builtin_bit_cast(_Float16, (uint16_t)(rg & 0xffffu));
@@ -761,10 +774,11 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     t_c += delta1;
                     dep = fmaf(w, t_c, dep);
                     cr = fmaf(w, sr, cr); cg = fmaf(w, sgc, cg); cb = fmaf(w, sb, cb);
-                    if (spec) last_t = t_c;                  // the next iteration's march_rays restarts its delta chain from rays_t
+                    if (spec && (s0 + k + 1) % spec == 0) last_t = t_c;   // the next iteration's march_rays restarts its delta chain from rays_t
                     if ((double)T < 1e-4) break;             // :890: this sample does not count as a completed step
                 }
                 steps_done += k;
+                if (spec == 1 && k >= 1 && cnt >= 2) ref_marched++;   // survived the first iteration of the sub-pass: the second one's sample
                 if (k < want) running = false;               // early stop, or deltas[0] == 0 (march ran out of samples)
             } else if (do_march && cnt) {
                 // keep the march's last_t chain consistent for a terminated ray that is still being dumped
@@ -810,8 +824,8 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             // The samples the reference marches are those of the iterations the ray entered alive (march-ahead within a sub-pass
             // may have produced one more).
             const uint32_t ds = ((blockIdx.x * kWaves + wid) % kDeathShards) * kSpecK;
-            for (uint32_t m = 0; m < n_step; m++) {
-                const uint32_t cdead = (uint32_t)__popcll(__ballot(active && !survive && steps_done == m));
+            for (uint32_t m = 0; m < n_step / spec; m++) {
+                const uint32_t cdead = (uint32_t)__popcll(__ballot(active && !survive && steps_done / spec == m));
                 if (lane == 0 && cdead) atomicAdd(&ra.death_shards[ds + m], cdead);
             }
             uint32_t rm = ref_marched;
@@ -921,6 +935,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         Ctl n = c;
         n.samples_marched = marched;
         n.n_alive = total_s + prefix_f + off_f[8];
+        uint32_t recent = c.n_alive - n.n_alive;   // deaths per reference iteration, most recent observation
         if (!c.spec) {
             n.last_n_alive = c.n_alive;
             n.last_n_step = c.n_step;
@@ -928,22 +943,27 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             n.samples_slots = c.samples_slots + (unsigned long long)c.n_alive * c.n_step;
             n.step = c.step + c.n_step;
         } else {
-            // K = c.n_step reference iterations of one sample each: n_alive(i + j) = n_alive(i) - deaths before j.  Each must have
-            // been run with n_step = clamp(N // n_alive, 1, 8) == 1, i.e. n_alive > N / 2; the loop would also have stopped at the
-            // first empty list.
-            uint32_t alive = c.n_alive, it = 0;
+            // K = c.n_step / q reference iterations of q = c.spec samples each: n_alive(i + j) = n_alive(i) - deaths before j.
+            // Each must have been run with n_step = clamp(N // n_alive, 1, 8) == q; the loop would also have stopped at the first
+            // empty list.
+            const uint32_t q = c.spec, K = c.n_step / q;
+            uint32_t alive = c.n_alive, it = 0, d_last = 0, d_prev = 0;
             unsigned long long slots = c.samples_slots;
             bool bad = false;
-            for (uint32_t j = 0; j < c.n_step; j++) {
+            for (uint32_t j = 0; j < K; j++) {
                 if (alive == 0) { bad = true; break; }            // the reference stops here; this launch ran on
-                if (j > 0 && (N / alive) != 1) bad = true;        // that iteration should have marched more than one sample
-                slots += alive;
+                const uint32_t want_q = N / alive;
+                if (j > 0 && (want_q < 1 ? 1u : (want_q > 8 ? 8u : want_q)) != q) bad = true;   // that iteration marches a different n_step
+                slots += (unsigned long long)alive * q;
                 it++;
                 n.last_n_alive = alive;
-                n.last_n_step = 1;
+                n.last_n_step = q;
                 alive -= deaths[j];
+                d_prev = d_last;
+                d_last = deaths[j];
             }
             if (alive != n.n_alive) bad = true;                   // bookkeeping must close: survivors == alive after the last iteration
+            recent = d_last > d_prev ? d_last : d_prev;            // the launch's last two iterations
             n.iters = c.iters + it;
             n.samples_slots = slots;
             n.step = c.step + c.n_step;
@@ -953,12 +973,21 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         uint32_t ns = n.n_alive ? N / n.n_alive : 8;
         n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
         n.done = (n.n_alive == 0 || n.step >= max_steps) ? 1 : 0;
-        // the next launch may cover several reference iterations: schedule in the n_step = 1 regime with room to spare
+        // The next launch may cover several reference iterations of q = n_step samples (q <= kSpecMaxQ; the kernel handles q = 1
+        // and 2, for which an iteration never straddles a two-sample sub-pass): as many as the recent death rate, with a factor kSpecSafety to spare, leaves room
+        // for above the n_alive at which the reference's n_step changes (N // n_alive == q  <=>  n_alive > N / (q + 1)).
         n.spec = 0;
-        if (spec_allowed && !n.done && !n.violated && n.n_step == 1 && n.n_alive > N / 2 + N / kSpecMarginDiv) {
-            const uint32_t room = max_steps - n.step;
-            const uint32_t K = room < kSpecK ? room : kSpecK;
-            if (K >= 2) { n.spec = 1; n.n_step = K; }
+        if (spec_allowed && !n.done && !n.violated && n.n_step <= kSpecMaxQ && n.n_alive > N / (n.n_step + 1)) {
+            const uint32_t q = n.n_step;
+            const uint32_t room = (max_steps - n.step) / q, headroom = n.n_alive - N / (q + 1) - 1;
+            // expected deaths per iteration: the recent count plus four standard deviations of a count that size (small frames)
+            uint32_t sq = 0;
+            while ((unsigned long long)(sq + 1) * (sq + 1) <= recent) sq++;
+            const unsigned long long rate = (unsigned long long)recent + 4ull * sq + 16ull;
+            uint32_t K = (uint32_t)((unsigned long long)headroom * 2u / (kSpecSafetyX2 * rate));
+            K = K < kSpecK / q ? K : kSpecK / q;
+            K = K < room ? K : room;
+            if (K >= 2) { n.spec = q; n.n_step = K * q; }
         }
         *nxt = n;
         for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
@@ -1081,6 +1110,7 @@ struct ngp_render_ctx {
     uint32_t* grid_lin = nullptr;           // x-fastest copy of the occupancy bitfield (k_build_linear), allocated on first use
     uint32_t* death_shards = nullptr;       // [kDeathShards][kSpecK] per-iteration death counts of a speculative launch
     bool no_spec = false;                   // set for the replay of a call whose speculation was violated
+    uint32_t spec_cooldown = 0;             // calls left without speculation after a violated one (consecutive frames are alike)
     float4* dump_rec = nullptr;             // lazily allocated: [max_rays][8]
     uint32_t* dump_iter = nullptr;          // [max_rays]
     Ctl* ctl = nullptr;          // device [2]
@@ -1199,7 +1229,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
                                                          (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
     // several reference iterations per launch (see Ctl): needs the end-of-call state on the host to verify it, no jitter
-    const uint32_t spec_allowed = (!g_spec_off && !ctx->no_spec && perturb == 0 && (sync || stats_host)) ? 1u : 0u;
+    const uint32_t spec_allowed = (!g_spec_off && !ctx->no_spec && ctx->spec_cooldown == 0 && perturb == 0 && (sync || stats_host)) ? 1u : 0u;
+    if (ctx->spec_cooldown && !ctx->no_spec) ctx->spec_cooldown--;
     k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
                                                  g_sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed);
 
@@ -1360,6 +1391,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
                 return NGP_ELAUNCH;
             }
             ctx->no_spec = true;
+            ctx->spec_cooldown = 8;
             const int rc2 = ngp_render_rays(ctx, model, rays_o, rays_d, nears, fars, N, dt_gamma, max_steps, perturb, weights_sum, depth, image,
                                             last_sigmas, last_rgbs, pad_value_host, stats_host, sync, stream);
             ctx->no_spec = false;
