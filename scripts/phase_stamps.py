@@ -21,8 +21,6 @@ b = buf.cpu().tolist(); tot = sum(b[:4])
 for n, v in zip(['march', 'encode+mlp tiles', 'composite', 'compaction+barrier'], b[:4]): print(f'{n:22s} {v:16d} {100*v/tot:6.2f} %')
 print(f"march passes {b[6]}: mean probes per lane-pass {b[5]/max(1,b[6])/64:.2f}, mean of per-wave max {b[4]/max(1,b[6]):.2f}  -> lane utilisation {b[5]/max(1,64*b[4]):.3f}")
 print(f"tiles {b[10]}: mean fill {b[11]/max(1,b[10]):.2f}/16; cycles per tile: encode+sigma {b[8]/max(1,b[10]):.0f}, colour {b[9]/max(1,b[10]):.0f}; whole tile phase per tile {b[1]/max(1,b[10]):.0f}")
-mx = b[12]; tot64, m64, t64 = mx >> 40, (mx >> 20) & 0xFFFFF, mx & 0xFFFFF
-print(f"chunks {b[14]}: mean chunk time {b[13]/max(1,b[14]):.0f} ticks; slowest chunk {tot64*64} ticks = march {m64*64} + tiles {t64*64} + rest {(tot64-m64-t64)*64}")
 import ctypes as C
 ms, n, u = C.c_double(), C.c_uint64(), C.c_double()
 lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
