@@ -63,7 +63,7 @@ def main():
     import torch.distributed as dist
 
     from nerfsafetyvalidation_amd import _lib
-    from nerfsafetyvalidation_amd.dist import gather_views
+    from nerfsafetyvalidation_amd.dist import gather_views_start
     from nerfsafetyvalidation_amd.nerf.utils import get_rays
     from nerfsafetyvalidation_amd.scene import StonehengeScene
 
@@ -97,17 +97,25 @@ def main():
     def view_of(step):                       # weak scaling: every rank renders its own camera each step
         return (step * world + rank) % n_views
 
+    pending = []
+
     def render_step(step, exchange=True):
         v = view_of(step)
         rays = get_rays(poses[v:v + 1], intr, H, W)
         out = model.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False)
         st = model.last_render_stats
-        if world > 1 and exchange:           # the path's one exchange step: all-gather the rendered tiles
-            gather_views(out["image"], world)
-            gather_views(out["depth"], world)
+        if world > 1 and exchange:
+            # the path's one exchange step: all-gather the rendered tile (rgb + depth in one tensor, one collective).  It runs on
+            # the backend's stream while the next view renders; the previous step's gather is completed first.
+            tile = torch.cat([out["image"], out["depth"].unsqueeze(-1)], -1)
+            if pending:
+                pending.pop().finish()
+            pending.append(gather_views_start(tile, world))
         return st["samples_marched"], st["iterations"], st["samples_slots"]
 
     def barrier():
+        while pending:
+            pending.pop().finish()        # every exchange started inside the timed region completes inside it
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -22,30 +22,49 @@ def shard_rows(H, rank, world_size, strip=8):
     return [r for r in range(H) if (r // strip) % world_size == rank]
 
 
-def gather_views(local, n_total, group=None):
-    """all_gather of per-rank stacks of rendered views.  local: [n_local, ...] (n_local may differ by one between ranks).
-    Returns [n_total, ...] on every rank, in global view order."""
+class _Gather:
+    """an all_gather in flight (gather_views_start); finish() returns the stitched result"""
+
+    def __init__(self, out, work, n_total, n_max, world, device):
+        self.out, self.work, self.n_total, self.n_max, self.world, self.device = out, work, n_total, n_max, world, device
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()            # nccl: the CURRENT stream waits for the collective; gloo: the host does
+            self.work = None
+        out = self.out if self.out.device == self.device else self.out.to(self.device)
+        pieces = []
+        for r in range(self.world):
+            lo, hi = shard_range(self.n_total, r, self.world)
+            pieces.append(out[r * self.n_max:r * self.n_max + (hi - lo)])
+        return torch.cat(pieces, 0)
+
+
+def gather_views_start(local, n_total, group=None):
+    """Start the all_gather of per-rank stacks of rendered views and return at once: the collective runs on the backend's own
+    stream (RCCL over xGMI) while the caller renders the next views; `.finish()` makes the current stream wait for it.
+    local: [n_local, ...] (n_local may differ by one between ranks)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
+        return _Gather(local, None, local.shape[0], local.shape[0], 1, local.device)
     world = dist.get_world_size(group)
     n_max = (n_total + world - 1) // world
     pad = n_max - local.shape[0]
     if pad > 0:
         local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    device = local.device
     if dist.get_backend(group) == "gloo" and local.is_cuda:
         # rehearsal mode (CPU collectives): stage through host memory; the production backend is nccl (= RCCL over xGMI)
-        host = local.contiguous().cpu()
-        out_h = host.new_empty((world * n_max,) + tuple(host.shape[1:]))
-        dist.all_gather_into_tensor(out_h, host, group=group)
-        out = out_h.to(local.device)
-    else:
-        out = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    pieces = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        pieces.append(out[r * n_max:r * n_max + (hi - lo)])
-    return torch.cat(pieces, 0)
+        local = local.contiguous().cpu()
+    out = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
+    work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=True)
+    return _Gather(out, work, n_total, n_max, world, device)
+
+
+def gather_views(local, n_total, group=None):
+    """all_gather of per-rank stacks of rendered views.  Returns [n_total, ...] on every rank, in global view order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    return gather_views_start(local, n_total, group).finish()
 
 
 def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None):
