@@ -214,7 +214,7 @@ typedef struct ngp_render_stats {
     uint32_t last_n_alive;        /* n_alive and n_step of the last iteration             */
     uint32_t last_n_step;
     uint32_t launches;            /* kernel launches enqueued (incl. run-ahead no-ops)    */
-    uint32_t replayed;            /* 1: a multi-iteration launch failed its verification and the call was rendered again, one reference iteration per launch */
+    uint32_t replayed;            /* launches that covered several reference iterations, failed their verification and were rolled back */
 } ngp_render_stats;
 
 typedef struct ngp_render_ctx ngp_render_ctx;  /* pinned status ring, events, scratch sizes */

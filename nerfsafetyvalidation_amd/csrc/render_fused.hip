@@ -57,25 +57,25 @@ struct Ctl {
     uint32_t n_alive, n_step, step, done;
     uint32_t iters, last_n_alive, last_n_step, pad;
     unsigned long long samples_marched, samples_slots;
-    uint32_t spec, violated, rsv[2];   // see "several reference iterations per launch" below
+    uint32_t spec, rollbacks, backoff, rsv;   // see "several reference iterations per launch" below
 };
 
 // Several reference iterations per launch.  While more than half of the N rays are alive the reference's schedule is
 // n_step = clamp(N // n_alive, 1, 8) = 1: one sample per ray and iteration, for dozens of iterations (50 of the 56 of an 800x800
 // Stonehenge frame), each paying a launch, the per-ray state round trip and a compaction for a single sample.  A launch with
-// `spec` set covers K = n_step consecutive reference iterations of one sample each: per ray it emulates the iteration
+// `spec` = q set covers K = n_step / q consecutive reference iterations of q samples each: per ray it emulates the iteration
 // boundaries exactly (march restarts from the re-accumulated rays_t, raymarching.cu:727,848) and the per-iteration death
-// counts give the n_alive sequence, so iterations / samples_slots / step are the reference's.  That is valid only if n_alive
-// stays above N/2 through the K iterations; K is sized from the recent death rate with a factor 2 to spare and the
-// assumption is VERIFIED afterwards: a violation
-// sets `violated` and ngp_render_rays renders the call again without it.  Not used with perturb (the jitter of an iteration
-// is seeded with the ray's index in that iteration's list).
-constexpr uint32_t kSpecK = 8;            // reference iterations per speculative launch
+// counts give the n_alive sequence, so iterations / samples_slots / step are the reference's.  That is valid only if
+// N // n_alive stays q through the K iterations.  K is GUESSED from the recent death rate and the launch is VERIFIED afterwards
+// by k_render_compact: on a violation every ray gets back the state the launch started from (each wave saves it when it
+// loads it), the alive list is handed on unchanged and the iteration is run again on its own -- a wrong guess costs one
+// launch, never a result.  Not used with perturb (the jitter of an iteration is seeded with the ray's index in that
+// iteration's list).
+constexpr uint32_t kSpecK = 8;            // most samples per ray in a launch that covers several reference iterations
 constexpr uint32_t kSpecMarginDiv = 16;   // first launch: entered only if n_alive - N/2 > N / kSpecMarginDiv
-// q = 2 works the same way but is not entered: a frame's last iterations, where n_step has grown to 2, end in a mass
-// die-off (rays reach `far` together) that no recent rate predicts -- measured: a replay per frame for 50 us saved.
-constexpr uint32_t kSpecMaxQ = 1;
-constexpr uint32_t kSpecSafetyX2 = 4;     // later launches: sized for 2 x the recent death rate (kSpecSafetyX2 / 2)
+// largest q for which a launch covers several iterations (K * q <= 8 samples per ray and launch, K >= 2)
+constexpr uint32_t kSpecMaxQ = 4;
+constexpr uint32_t kSpecSafetyX2 = 2;     // later launches: sized for kSpecSafetyX2 / 2 = 1.5 x the recent death rate
 constexpr int kDeathShards = 64;
 // work-queue heads: one per shard (chunk c belongs to shard c & 7), each on its own 128-byte line, two sets (ping-pong with Ctl)
 struct QueueHeads { uint32_t head[8][32]; };
@@ -533,6 +533,7 @@ struct RenderArgs {
     QueueHeads* heads;                // its work-queue heads (zeroed by the previous k_render_compact / k_render_init)
     unsigned long long* stat_shards;  // [kStatShards] marched-sample counters (summed by k_render_compact)
     uint32_t* death_shards;           // [kDeathShards][kSpecK] rays that died in the k-th iteration of a speculative launch
+    float4* backup;                   // [N][2] per-ray state before a speculative launch (restored if its verification fails)
     const uint8_t* bitfield;
     uint32_t cascade, grid_size, max_steps, perturb;
     float dt_gamma;
@@ -637,10 +638,13 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             cr = ra.image[(size_t)ray * 3]; cg = ra.image[(size_t)ray * 3 + 1]; cb = ra.image[(size_t)ray * 3 + 2];
             S.od[lane][0] = dda.ox; S.od[lane][1] = dda.oy; S.od[lane][2] = dda.oz;
             S.od[lane][3] = dda.dx; S.od[lane][4] = dda.dy; S.od[lane][5] = dda.dz;
+            if (spec) {   // the state this launch starts from, should its verification fail (k_render_compact restores it)
+                ra.backup[(size_t)ray * 2] = make_float4(t_c, ws, dep, ra.sample_hash ? __uint_as_float(ra.sample_hash[ray]) : 0.0f);
+                ra.backup[(size_t)ray * 2 + 1] = make_float4(cr, cg, cb, 0.0f);
+            }
         }
         float last_m = last_t;               // march-side copy of last_t
         float geo_tc = t_c;                  // march-side copy of rays_t across the iteration boundaries of a speculative launch
-        uint32_t ref_marched = 0;            // speculative launches: samples the reference's iterations march for this ray
         uint32_t emitted = 0;                // samples marched by this lane in this launch
         uint32_t hsh = 0;
         if (active && ra.sample_hash) hsh = ra.sample_hash[ray];
@@ -654,7 +658,8 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             // ---- 1. march (raymarching.cu:757-813), lane = ray.  A ray whose compositing already stopped is not marched
             //         further unless the caller asked for the reference's last-iteration tensors.
             uint32_t cnt = 0, n_probes = 0;
-            const bool do_march = active && (running || ra.last_sigmas != nullptr);
+            // (a launch that covers several iterations is never the reference's last one: nothing of it is dumped)
+            const bool do_march = active && (running || (ra.last_sigmas != nullptr && !spec));
             if (do_march) {
                 float x, y, z, dt;
                 while (t_march < far && cnt < want) {
@@ -691,7 +696,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             if (!__any(cnt != 0)) {
                 // nothing to evaluate in this sub-pass for the whole wave
                 if (running && cnt < want) running = false;
-                if (ra.last_sigmas && active)
+                if (ra.last_sigmas && active && !spec)
                     for (uint32_t k = 0; k < want; k++) dump_row(ra, entry, ray, n_step, s0 + k, ra.pad_sigma, ra.pad_r, ra.pad_g, ra.pad_b);
                 if (!ra.last_sigmas && !__any(running)) break;
                 continue;
@@ -748,12 +753,6 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             }
             NGP_STAMP(1)
             // ---- 3. composite (raymarching.cu:860-897), lane = ray
-            if (running && spec) {
-                // samples the reference marches: every sample of an iteration the ray enters alive (march_rays runs before
-                // composite_rays).  spec == 2: the sub-pass is one iteration; spec == 1: it holds two, the second counts only if the
-                // first is survived (added below)
-                ref_marched += spec == 1 ? (cnt ? 1u : 0u) : cnt;
-            }
             if (running) {
                 uint32_t k = 0;
                 for (; k < cnt; k++) {
@@ -778,13 +777,12 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     if ((double)T < 1e-4) break;             // :890: this sample does not count as a completed step
                 }
                 steps_done += k;
-                if (spec == 1 && k >= 1 && cnt >= 2) ref_marched++;   // survived the first iteration of the sub-pass: the second one's sample
                 if (k < want) running = false;               // early stop, or deltas[0] == 0 (march ran out of samples)
             } else if (do_march && cnt) {
                 // keep the march's last_t chain consistent for a terminated ray that is still being dumped
                 last_t = S.t[lane * kCh + cnt - 1] + S.dt[lane * kCh + cnt - 1];
             }
-            if (ra.last_sigmas && active) {
+            if (ra.last_sigmas && active && !spec) {   // (a multi-iteration launch is never the reference's last iteration)
                 for (uint32_t k = 0; k < want; k++) {
                     const uint32_t slot = lane * kCh + k;
                     if (k < cnt)
@@ -828,7 +826,10 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                 const uint32_t cdead = (uint32_t)__popcll(__ballot(active && !survive && steps_done / spec == m));
                 if (lane == 0 && cdead) atomicAdd(&ra.death_shards[ds + m], cdead);
             }
-            uint32_t rm = ref_marched;
+            // samples the reference marches for this ray: all of every iteration it enters alive (march_rays runs before
+            // composite_rays); a ray that completed steps_done samples entered iterations 0 .. steps_done / spec
+            const uint32_t entered = survive ? n_step : (steps_done / spec + 1) * spec;
+            uint32_t rm = active ? (emitted < entered ? emitted : entered) : 0u;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) rm += __shfl_xor(rm, off, 64);
             wave_samples = rm;
@@ -868,7 +869,10 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
                                                          const uint32_t* __restrict__ chunk_count, int32_t* __restrict__ alive_out, uint32_t N,
                                                          uint32_t max_steps, const unsigned long long* __restrict__ stat_shards,
                                                          QueueHeads* __restrict__ nxt_heads, unsigned long long* __restrict__ host_slot, uint32_t seq,
-                                                         uint32_t* __restrict__ death_shards, uint32_t spec_allowed) {
+                                                         uint32_t* __restrict__ death_shards, uint32_t spec_allowed, const int32_t* __restrict__ alive_in,
+                                                         const float4* __restrict__ backup, float* __restrict__ rays_t, float* __restrict__ weights_sum,
+                                                         float* __restrict__ depth, float* __restrict__ image, uint32_t* __restrict__ sample_hash,
+                                                         unsigned long long* stat_shards_rw) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
     const Ctl c = *cur;
@@ -884,6 +888,59 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
     const uint32_t g = blockIdx.x;
     if (g >= n_blocks) return;
     const uint32_t first = g * 8;
+    // ---- a launch that covered several reference iterations is verified first (every block reaches the same verdict) ----
+    __shared__ uint32_t deaths[kSpecK];
+    __shared__ uint32_t verdict_bad;
+    if (threadIdx.x < kSpecK) {
+        uint32_t d = 0;
+        if (c.spec)
+            for (int sh = 0; sh < kDeathShards; sh++) d += death_shards[sh * kSpecK + threadIdx.x];
+        deaths[threadIdx.x] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // K = c.n_step / q reference iterations of q = c.spec samples each: n_alive(i + j) = n_alive(i) - deaths before j.  Each must
+        // have been run with n_step = clamp(N // n_alive, 1, 8) == q, and the loop would have stopped at the first empty list.
+        uint32_t bad = 0;
+        if (c.spec) {
+            const uint32_t q = c.spec, K = c.n_step / q;
+            uint32_t alive = c.n_alive;
+            for (uint32_t j = 0; j < K; j++) {
+                if (alive == 0) { bad = 1; break; }
+                const uint32_t want_q = N / alive;
+                if (j > 0 && (want_q < 1 ? 1u : (want_q > 8 ? 8u : want_q)) != q) bad = 1;
+                alive -= deaths[j];
+            }
+        }
+        verdict_bad = bad;
+    }
+    __syncthreads();
+    if (verdict_bad) {
+        // ROLLBACK: the launch was not equivalent to the reference's iterations.  Every ray it processed gets the state it
+        // started from back, the alive list is handed on unchanged, and the iteration is run again on its own.
+        for (uint32_t e = first * 64 + threadIdx.x; e < (first + 8) * 64 && e < c.n_alive; e += 256) {
+            const int32_t ray = alive_in[e];
+            const float4 a = backup[(size_t)ray * 2], b = backup[(size_t)ray * 2 + 1];
+            rays_t[ray] = a.x; weights_sum[ray] = a.y; depth[ray] = a.z;
+            if (sample_hash) sample_hash[ray] = __float_as_uint(a.w);
+            image[(size_t)ray * 3] = b.x; image[(size_t)ray * 3 + 1] = b.y; image[(size_t)ray * 3 + 2] = b.z;
+            alive_out[e] = ray;
+        }
+        if (g == n_blocks - 1 && threadIdx.x == 0) {
+            Ctl n = c;
+            n.spec = 0;
+            const uint32_t ns = c.n_alive ? N / c.n_alive : 8;
+            n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
+            n.rollbacks = c.rollbacks + 1;
+            n.backoff = 2;                                        // the next two iterations run one per launch
+            for (int i = 0; i < kDeathShards * (int)kSpecK; i++) death_shards[i] = 0;
+            for (int i = 0; i < kStatShards; i++) stat_shards_rw[i] = 0ull;   // the discarded launch's sample counts
+            *nxt = n;
+            for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
+            publish_status(host_slot, n, seq);
+        }
+        return;
+    }
     uint32_t pf = 0, ps = 0, tf = 0;     // fast / slow survivors before this block, SLOW survivors in total
     for (uint32_t j = threadIdx.x; j < n_chunks; j += 256) {
         const uint32_t v = chunk_count[j];
@@ -919,21 +976,13 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         if (lane < ns) alive_out[prefix_s + off_s[ci] + lane] = staging[(size_t)(first + ci) * 64 + 63 - lane];
         if (lane < nf) alive_out[total_s + prefix_f + off_f[ci] + lane] = staging[(size_t)(first + ci) * 64 + lane];
     }
-    unsigned long long marched = threadIdx.x < (uint32_t)kStatShards ? stat_shards[threadIdx.x] : 0ull;   // kStatShards == 64: wave 0
+    unsigned long long marched = threadIdx.x < (uint32_t)kStatShards ? stat_shards_rw[threadIdx.x] : 0ull;   // kStatShards == 64: wave 0
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) marched += __shfl_down(marched, off, 64);
-    // deaths per iteration of a speculative launch (wave 1 sums the shards; every block does, only the last one uses them)
-    __shared__ uint32_t deaths[kSpecK];
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + kSpecK) {
-        uint32_t d = 0;
-        if (c.spec)
-            for (int sh = 0; sh < kDeathShards; sh++) d += death_shards[sh * kSpecK + (threadIdx.x - 64)];
-        deaths[threadIdx.x - 64] = d;
-    }
-    __syncthreads();
     if (g == n_blocks - 1 && threadIdx.x == 0) {
         Ctl n = c;
-        n.samples_marched = marched;
+        n.samples_marched = c.samples_marched + marched;          // per-launch counters: folded in here, reset below
+        for (int i = 0; i < kStatShards; i++) stat_shards_rw[i] = 0ull;
         n.n_alive = total_s + prefix_f + off_f[8];
         uint32_t recent = c.n_alive - n.n_alive;   // deaths per reference iteration, most recent observation
         if (!c.spec) {
@@ -943,44 +992,34 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             n.samples_slots = c.samples_slots + (unsigned long long)c.n_alive * c.n_step;
             n.step = c.step + c.n_step;
         } else {
-            // K = c.n_step / q reference iterations of q = c.spec samples each: n_alive(i + j) = n_alive(i) - deaths before j.
-            // Each must have been run with n_step = clamp(N // n_alive, 1, 8) == q; the loop would also have stopped at the first
-            // empty list.
             const uint32_t q = c.spec, K = c.n_step / q;
-            uint32_t alive = c.n_alive, it = 0, d_last = 0, d_prev = 0;
+            uint32_t alive = c.n_alive, d_last = 0, d_prev = 0;
             unsigned long long slots = c.samples_slots;
-            bool bad = false;
             for (uint32_t j = 0; j < K; j++) {
-                if (alive == 0) { bad = true; break; }            // the reference stops here; this launch ran on
-                const uint32_t want_q = N / alive;
-                if (j > 0 && (want_q < 1 ? 1u : (want_q > 8 ? 8u : want_q)) != q) bad = true;   // that iteration marches a different n_step
                 slots += (unsigned long long)alive * q;
-                it++;
                 n.last_n_alive = alive;
                 n.last_n_step = q;
                 alive -= deaths[j];
                 d_prev = d_last;
                 d_last = deaths[j];
             }
-            if (alive != n.n_alive) bad = true;                   // bookkeeping must close: survivors == alive after the last iteration
             recent = d_last > d_prev ? d_last : d_prev;            // the launch's last two iterations
-            n.iters = c.iters + it;
+            n.iters = c.iters + K;
             n.samples_slots = slots;
             n.step = c.step + c.n_step;
-            if (bad) n.violated = 1;
-            for (int i = threadIdx.x; i < kDeathShards * (int)kSpecK; i++) death_shards[i] = 0;   // (one thread: 512 words, once per launch)
+            for (int i = 0; i < kDeathShards * (int)kSpecK; i++) death_shards[i] = 0;
         }
         uint32_t ns = n.n_alive ? N / n.n_alive : 8;
         n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
         n.done = (n.n_alive == 0 || n.step >= max_steps) ? 1 : 0;
-        // The next launch may cover several reference iterations of q = n_step samples (q <= kSpecMaxQ; the kernel handles q = 1
-        // and 2, for which an iteration never straddles a two-sample sub-pass): as many as the recent death rate, with a factor kSpecSafety to spare, leaves room
-        // for above the n_alive at which the reference's n_step changes (N // n_alive == q  <=>  n_alive > N / (q + 1)).
+        // The next launch may cover several reference iterations of q = n_step samples (K * q <= 8): as many as the recent death
+        // rate (plus four standard deviations of a count that size) leaves room for above the n_alive at which the reference's
+        // n_step changes (N // n_alive == q  <=>  n_alive > N / (q + 1)).  A wrong guess costs one launch (rollback above).
         n.spec = 0;
-        if (spec_allowed && !n.done && !n.violated && n.n_step <= kSpecMaxQ && n.n_alive > N / (n.n_step + 1)) {
+        if (n.backoff) n.backoff--;
+        else if (spec_allowed && !n.done && n.n_step <= kSpecMaxQ && n.n_alive > N / (n.n_step + 1)) {
             const uint32_t q = n.n_step;
             const uint32_t room = (max_steps - n.step) / q, headroom = n.n_alive - N / (q + 1) - 1;
-            // expected deaths per iteration: the recent count plus four standard deviations of a count that size (small frames)
             uint32_t sq = 0;
             while ((unsigned long long)(sq + 1) * (sq + 1) <= recent) sq++;
             const unsigned long long rate = (unsigned long long)recent + 4ull * sq + 16ull;
@@ -1109,8 +1148,7 @@ struct ngp_render_ctx {
     unsigned long long* coarse = nullptr;   // coarse occupancy bits (<= 8 KB)
     uint32_t* grid_lin = nullptr;           // x-fastest copy of the occupancy bitfield (k_build_linear), allocated on first use
     uint32_t* death_shards = nullptr;       // [kDeathShards][kSpecK] per-iteration death counts of a speculative launch
-    bool no_spec = false;                   // set for the replay of a call whose speculation was violated
-    uint32_t spec_cooldown = 0;             // calls left without speculation after a violated one (consecutive frames are alike)
+    float4* backup = nullptr;               // [max_rays][2] per-ray state a speculative launch starts from (for its rollback)
     float4* dump_rec = nullptr;             // lazily allocated: [max_rays][8]
     uint32_t* dump_iter = nullptr;          // [max_rays]
     Ctl* ctl = nullptr;          // device [2]
@@ -1176,6 +1214,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
     ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
     ok &= hipMalloc(&c->death_shards, (size_t)kDeathShards * kSpecK * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&c->backup, (size_t)max_rays * 2 * sizeof(float4)) == hipSuccess;
     ok &= hipMalloc(&c->heads, 2 * sizeof(QueueHeads)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
     ok &= hipHostMalloc(&c->status, kRing * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -1199,7 +1238,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
-    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->death_shards); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
+    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->death_shards); (void)hipFree(c->backup); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -1228,9 +1267,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
     k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
                                                          (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
-    // several reference iterations per launch (see Ctl): needs the end-of-call state on the host to verify it, no jitter
-    const uint32_t spec_allowed = (!g_spec_off && !ctx->no_spec && ctx->spec_cooldown == 0 && perturb == 0 && (sync || stats_host)) ? 1u : 0u;
-    if (ctx->spec_cooldown && !ctx->no_spec) ctx->spec_cooldown--;
+    // several reference iterations per launch (see Ctl): not with jitter
+    const uint32_t spec_allowed = (!g_spec_off && perturb == 0) ? 1u : 0u;
     k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
                                                  g_sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed);
 
@@ -1241,6 +1279,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
     ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count; ra.stat_shards = ctx->stat_shards;
     ra.death_shards = ctx->death_shards;
+    ra.backup = ctx->backup;
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
@@ -1326,7 +1365,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
                                                            ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1, ctx->death_shards,
-                                                           spec_allowed);
+                                                           spec_allowed, ctx->alive[cur], ctx->backup, ctx->rays_t, weights_sum, depth, image,
+                                                           g_sample_hash, ctx->stat_shards);
         launched++;
         launches += 2;
         // consume every status that has already landed; block only when too far ahead
@@ -1357,7 +1397,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             ub = (uint32_t)w & 0x7FFFFFFFu;
             if ((w >> 31) & 1ull) { done = true; break; }
         }
-        if (launched > max_steps + 8u) {  // cannot happen: every iteration advances step by >= 1
+        if (launched > 2u * max_steps + 16u) {  // cannot happen: every launch advances step by >= 1 or is the rollback of one that did
             set_error("render_rays: iteration bound exceeded");
             return NGP_ELAUNCH;
         }
@@ -1383,21 +1423,6 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
             return NGP_ELAUNCH;
         }
-        if (fin.violated) {
-            // a launch that covered several reference iterations turned out not to be equivalent to them (more than the margin
-            // of rays died inside it): render the call again, one reference iteration per launch
-            if (ctx->no_spec) {
-                set_error("render_rays: schedule verification failed without speculation (internal error)");
-                return NGP_ELAUNCH;
-            }
-            ctx->no_spec = true;
-            ctx->spec_cooldown = 8;
-            const int rc2 = ngp_render_rays(ctx, model, rays_o, rays_d, nears, fars, N, dt_gamma, max_steps, perturb, weights_sum, depth, image,
-                                            last_sigmas, last_rgbs, pad_value_host, stats_host, sync, stream);
-            ctx->no_spec = false;
-            if (stats_host && rc2 == NGP_OK) stats_host->replayed = 1;
-            return rc2;
-        }
         if (stats_host) {
             stats_host->samples_marched = fin.samples_marched;
             stats_host->samples_slots = fin.samples_slots;
@@ -1406,7 +1431,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             stats_host->last_n_alive = fin.last_n_alive;
             stats_host->last_n_step = fin.last_n_step;
             stats_host->launches = launches;
-            stats_host->replayed = 0;
+            stats_host->replayed = fin.rollbacks;
             prof_add_units("k_render_iter", (double)fin.samples_marched);
         }
     }

@@ -225,9 +225,9 @@ def test_fused_vs_operator_loop_across_configurations(device, bound, dt_gamma, p
 
 
 def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
-    """A launch covering several reference iterations assumes n_alive stays above N/2.  With a density so high that most
-    rays saturate within a few samples the assumption fails inside the first launch: the device flags it, the call is
-    rendered again one iteration per launch, and the result equals the plain loop's bit for bit."""
+    """A launch covering several reference iterations assumes N // n_alive does not change inside it.  With a density so high
+    that most rays saturate within a few samples the assumption fails inside the first launch: the device detects it, restores
+    every ray's state, runs the iteration again on its own, and the result equals the plain loop's bit for bit."""
     from nerfsafetyvalidation_amd import _lib
     sc = setup[0]
     model = sc.build_model(device)
@@ -246,7 +246,7 @@ def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
     finally:
         model.density_scale = old_scale
         lib.ngp_debug_disable_march_queue(0)
-    assert outs[0][1]["replayed"] == 1 and outs[256][1]["replayed"] == 0
+    assert outs[0][1]["replayed"] >= 1 and outs[256][1]["replayed"] == 0       # number of rolled-back launches
     assert torch.equal(outs[0][0], outs[256][0])
     for key in ("samples_marched", "samples_slots", "iterations"):
         assert outs[0][1][key] == outs[256][1][key], key
