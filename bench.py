@@ -102,7 +102,8 @@ def main():
     def render_step(step, exchange=True):
         v = view_of(step)
         rays = get_rays(poses[v:v + 1], intr, H, W)
-        out = model.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False)
+        # frame_width: scheduling hint of this build (ngp_render_ctx_set_frame_width); the rendered values do not depend on it
+        out = model.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False, frame_width=W)
         st = model.last_render_stats
         if world > 1 and exchange:
             # the path's one exchange step: all-gather the rendered tile (rgb + depth in one tensor, one collective).  It runs on

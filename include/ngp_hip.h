@@ -224,6 +224,13 @@ typedef struct ngp_render_ctx ngp_render_ctx;  /* pinned status ring, events, sc
 NGP_API int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out);
 NGP_API int ngp_render_ctx_destroy(ngp_render_ctx* ctx);
 
+/* Scheduling hint: the rays of the following ngp_render_rays calls are the pixels of row-major frames `width` pixels wide
+ * (what get_rays produces, nerf/utils.py:52-116); 0 = make no assumption (the default).  The renderer then starts its list of
+ * live rays in 4x4-pixel tiles instead of row order, which makes the hash-grid gathers of neighbouring samples share cache
+ * lines.  Results do not depend on it (the order of rays_alive enters no output when perturb == 0; with perturb the hint is
+ * ignored, because march_rays seeds its jitter with the list index, raymarching.cu:819). */
+NGP_API int ngp_render_ctx_set_frame_width(ngp_render_ctx* ctx, uint32_t width);
+
 /* rays_o/rays_d [N,3] f32, nears/fars [N] f32 (from ngp_near_far_from_aabb).
  * Outputs weights_sum [N], depth [N], image [N,3] f32: the accumulated values BEFORE the
  * background mix / depth normalisation of renderer.py:375-378 (done by the caller as in the
@@ -282,7 +289,7 @@ NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
 /* Diagnostics: uint32[N] device buffer receiving, per ray, an FNV-1a hash over the bit patterns of (dt, deltas[1]) of every
  * sample the fused renderer marched, in order (NULL = off).  Lets a test prove the fused path's sample sequence equal to
  * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 0 / bit 1 disable the coarse occupancy filter, bit 2 the
- * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
+ * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
 

@@ -120,8 +120,10 @@ class FusedModel:
             self._ctx, self._ctx_rays = h, N
         return self._ctx
 
-    def render(self, net_bitfield_owner, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb, want_last=True, want_stats=True):
-        """eval-mode body of run_cuda -> weights_sum [N], depth [N], image [N,3], last sigmas, last rgbs"""
+    def render(self, net_bitfield_owner, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb, want_last=True, want_stats=True,
+               frame_width=0):
+        """eval-mode body of run_cuda -> weights_sum [N], depth [N], image [N,3], last sigmas, last rgbs.
+        frame_width: the rays are the pixels of row-major frames this wide (scheduling hint, results do not depend on it)"""
         bitfield = net_bitfield_owner.density_bitfield
         N = rays_o.shape[0]
         dev = rays_o.device
@@ -135,6 +137,7 @@ class FusedModel:
         lib = _lib.lib()
         ctx = self._context(N)
         need_stats = want_stats or want_last
+        _lib.check(lib.ngp_render_ctx_set_frame_width(ctx, int(frame_width or 0)), "render_ctx_set_frame_width")
         _lib.check(lib.ngp_render_rays(ctx, C.byref(m), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()),
                                        _lib.ptr(fars.contiguous()), N, float(dt_gamma), int(max_steps), int(perturb), _lib.ptr(weights_sum),
                                        _lib.ptr(depth), _lib.ptr(image), _lib.ptr(last_s), _lib.ptr(last_c),

@@ -72,6 +72,7 @@ SIGNATURES = {
     "ngp_adam_step": [_vp, _vp, _vp, _vp, C.c_uint64, _f32, _f32, _f32, _f32, _u32, _f32, _vp],
     "ngp_render_ctx_create": [_u32, C.POINTER(_vp)],
     "ngp_render_ctx_destroy": [_vp],
+    "ngp_render_ctx_set_frame_width": [_vp, _u32],
     "ngp_render_rays": [_vp, C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                         C.POINTER(C.c_float), C.POINTER(RenderStats), _int, _vp],
     "ngp_network_forward": [C.POINTER(ModelStruct), _vp, _vp, _u32, _vp, _vp, _vp],

@@ -71,11 +71,12 @@ struct Ctl {
 // loads it), the alive list is handed on unchanged and the iteration is run again on its own -- a wrong guess costs one
 // launch, never a result.  Not used with perturb (the jitter of an iteration is seeded with the ray's index in that
 // iteration's list).
-constexpr uint32_t kSpecK = 8;            // most samples per ray in a launch that covers several reference iterations
+constexpr uint32_t kSpecK = 8;            // most reference iterations per launch
 constexpr uint32_t kSpecMarginDiv = 16;   // first launch: entered only if n_alive - N/2 > N / kSpecMarginDiv
 // largest q for which a launch covers several iterations (K * q <= 8 samples per ray and launch, K >= 2)
-constexpr uint32_t kSpecMaxQ = 4;
-constexpr uint32_t kSpecSafetyX2 = 2;     // later launches: sized for kSpecSafetyX2 / 2 = 1.5 x the recent death rate
+constexpr uint32_t kSpecMaxQ = 8;
+constexpr uint32_t kSpecMaxSamples = 32;  // samples per ray and launch in the n_step >= 5 regimes
+constexpr uint32_t kSpecSafetyX2 = 3;     // later launches: sized for kSpecSafetyX2 / 2 = 1.5 x the recent death rate
 constexpr int kDeathShards = 64;
 // work-queue heads: one per shard (chunk c belongs to shard c & 7), each on its own 128-byte line, two sets (ping-pong with Ctl)
 struct QueueHeads { uint32_t head[8][32]; };
@@ -906,11 +907,13 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             const uint32_t q = c.spec, K = c.n_step / q;
             uint32_t alive = c.n_alive;
             for (uint32_t j = 0; j < K; j++) {
-                if (alive == 0) { bad = 1; break; }
+                if (alive == 0) break;                            // the reference stops here; the rest of the launch had no ray to touch
                 const uint32_t want_q = N / alive;
                 if (j > 0 && (want_q < 1 ? 1u : (want_q > 8 ? 8u : want_q)) != q) bad = 1;
                 alive -= deaths[j];
             }
+            // the caller wants the reference's last-iteration tensors: that iteration has to run on its own (bit 1 of spec_allowed)
+            if ((spec_allowed & 2u) && alive == 0) bad = 1;
         }
         verdict_bad = bad;
     }
@@ -995,8 +998,11 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             const uint32_t q = c.spec, K = c.n_step / q;
             uint32_t alive = c.n_alive, d_last = 0, d_prev = 0;
             unsigned long long slots = c.samples_slots;
+            uint32_t it = 0;
             for (uint32_t j = 0; j < K; j++) {
+                if (alive == 0) break;                            // iterations the reference does not run
                 slots += (unsigned long long)alive * q;
+                it++;
                 n.last_n_alive = alive;
                 n.last_n_step = q;
                 alive -= deaths[j];
@@ -1004,9 +1010,9 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
                 d_last = deaths[j];
             }
             recent = d_last > d_prev ? d_last : d_prev;            // the launch's last two iterations
-            n.iters = c.iters + K;
+            n.iters = c.iters + it;
             n.samples_slots = slots;
-            n.step = c.step + c.n_step;
+            n.step = c.step + it * q;
             for (int i = 0; i < kDeathShards * (int)kSpecK; i++) death_shards[i] = 0;
         }
         uint32_t ns = n.n_alive ? N / n.n_alive : 8;
@@ -1017,14 +1023,22 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         // n_step changes (N // n_alive == q  <=>  n_alive > N / (q + 1)).  A wrong guess costs one launch (rollback above).
         n.spec = 0;
         if (n.backoff) n.backoff--;
-        else if (spec_allowed && !n.done && n.n_step <= kSpecMaxQ && n.n_alive > N / (n.n_step + 1)) {
+        else if (spec_allowed && !n.done && n.n_step <= kSpecMaxQ && (n.n_step == 8 || n.n_alive > N / (n.n_step + 1))) {
             const uint32_t q = n.n_step;
-            const uint32_t room = (max_steps - n.step) / q, headroom = n.n_alive - N / (q + 1) - 1;
+            const bool own_last = (spec_allowed & 2u) != 0;     // the last iteration must not be part of such a launch
+            uint32_t room = (max_steps - n.step) / q;
+            if (own_last && room) room--;
+            const uint32_t headroom = n.n_alive - (q == 8 ? 0u : N / (q + 1)) - 1;
             uint32_t sq = 0;
             while ((unsigned long long)(sq + 1) * (sq + 1) <= recent) sq++;
             const unsigned long long rate = (unsigned long long)recent + 4ull * sq + 16ull;
-            uint32_t K = (uint32_t)((unsigned long long)headroom * 2u / (kSpecSafetyX2 * rate));
-            K = K < kSpecK / q ? K : kSpecK / q;
+            const uint32_t safety_x2 = (spec_allowed >> 8) ? (spec_allowed >> 8) : kSpecSafetyX2;   // (diagnostics may override the factor)
+            uint32_t K = (uint32_t)((unsigned long long)headroom * 2u / (safety_x2 * rate));
+            // at most 8 samples per ray and launch while n_step is small; in the n_step >= 5 regimes (few rays, every launch
+            // latency-bound) up to kSpecMaxSamples.  With n_step = 8 the guess cannot fail: N // n_alive only grows as rays die.
+            const uint32_t cap_samples = q <= 4 ? 8u : kSpecMaxSamples;
+            const uint32_t capK = cap_samples / q < kSpecK ? cap_samples / q : kSpecK;
+            K = (q == 8 && !own_last) ? capK : (K < capK ? K : capK);
             K = K < room ? K : room;
             if (K >= 2) { n.spec = q; n.n_step = K * q; }
         }
@@ -1038,14 +1052,22 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
                                                       int32_t* __restrict__ alive, float* __restrict__ weights_sum, float* __restrict__ depth,
                                                       float* __restrict__ image, Ctl* __restrict__ ctl, uint32_t max_steps,
                                                       uint32_t* __restrict__ sample_hash, unsigned long long* __restrict__ stat_shards,
-                                                      QueueHeads* __restrict__ heads, uint32_t* __restrict__ death_shards, uint32_t spec_allowed) {
+                                                      QueueHeads* __restrict__ heads, uint32_t* __restrict__ death_shards, uint32_t spec_allowed,
+                                                      uint32_t tile_w) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n < (uint32_t)kStatShards) stat_shards[n] = 0ull;
     if (n < (uint32_t)kDeathShards * kSpecK) death_shards[n] = 0;
     if (n < 16) heads[n >> 3].head[n & 7][0] = 0;
     if (n < N) {
         if (sample_hash) sample_hash[n] = 2166136261u;
-        alive[n] = (int32_t)n;
+        // the order of the alive list is free for perturb == 0 (see k_render_iter): with a known frame width the list starts in
+        // 4x4-pixel tiles, so that the 16 samples of one MLP tile gather from neighbouring cells
+        uint32_t first = n;
+        if (tile_w) {
+            const uint32_t t = n >> 4, in = n & 15u, per_row = tile_w >> 2;
+            first = ((t / per_row) * 4u + (in >> 2)) * tile_w + (t % per_row) * 4u + (in & 3u);
+        }
+        alive[n] = (int32_t)first;
         rays_t[n] = nears[n];
         weights_sum[n] = 0; depth[n] = 0;
         image[(size_t)n * 3] = 0; image[(size_t)n * 3 + 1] = 0; image[(size_t)n * 3 + 2] = 0;
@@ -1055,9 +1077,10 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
         c.n_alive = N;
         c.n_step = 1;  // clamp(N // N, 1, 8)
         c.done = (N == 0 || max_steps == 0) ? 1 : 0;
-        if (spec_allowed && !c.done && N > N / 2 + N / kSpecMarginDiv && max_steps >= 2) {   // see Ctl: several iterations per launch
+        const uint32_t room = (spec_allowed & 2u) ? (max_steps ? max_steps - 1 : 0) : max_steps;   // bit 1: the last iteration runs on its own
+        if (spec_allowed && !c.done && N > N / 2 + N / kSpecMarginDiv && room >= 2) {   // see Ctl: several iterations per launch
             c.spec = 1;
-            c.n_step = max_steps < kSpecK ? max_steps : kSpecK;
+            c.n_step = room < kSpecK ? room : kSpecK;
         }
         ctl[0] = c;
         ctl[1] = c;
@@ -1141,6 +1164,7 @@ using namespace ngp;
 
 struct ngp_render_ctx {
     uint32_t max_rays = 0;
+    uint32_t frame_width = 0;               // ngp_render_ctx_set_frame_width: rays are the pixels of row-major frames this wide (0: unknown)
     int32_t* alive[2] = {nullptr, nullptr};
     int32_t* staging = nullptr;
     uint32_t* chunk_count = nullptr;
@@ -1168,6 +1192,8 @@ static bool g_coarse_off = false;
 static bool g_lin_off = false;
 static bool g_jump_off = false;
 static bool g_spec_off = false;
+static bool g_tile_off = false;         // bit 13 of the debug flags: ignore the frame-width hint
+static uint32_t g_spec_safety_x2 = 0;   // 0: kSpecSafetyX2
 static bool g_sort_off = false;
 
 static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
@@ -1235,6 +1261,12 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     return NGP_OK;
 }
 
+int ngp_render_ctx_set_frame_width(ngp_render_ctx* ctx, uint32_t width) {
+    NGP_REQUIRE(ctx, "render_ctx_set_frame_width: null context");
+    ctx->frame_width = width;
+    return NGP_OK;
+}
+
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
@@ -1268,9 +1300,13 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
                                                          (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
     // several reference iterations per launch (see Ctl): not with jitter
-    const uint32_t spec_allowed = (!g_spec_off && perturb == 0) ? 1u : 0u;
+    // bit 0: launches may cover several reference iterations; bit 1: but never the last one (its tensors are wanted); bits 8..: diagnostics
+    const uint32_t spec_allowed = (!g_spec_off && perturb == 0) ? (1u | (last_sigmas ? 2u : 0u) | (g_spec_safety_x2 << 8)) : 0u;
+    // scheduling hint (ngp_render_ctx_set_frame_width): whole rows of 4x4-pixel tiles only; not with jitter (seeded with the list index)
+    const uint32_t fw = ctx->frame_width;
+    const uint32_t tile_w = (perturb == 0 && !g_tile_off && fw >= 4 && fw % 4 == 0 && N % (4 * fw) == 0) ? fw : 0u;
     k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
-                                                 g_sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed);
+                                                 g_sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed, tile_w);
 
     RenderArgs ra = {};
     ra.rays_o = rays_o; ra.rays_d = rays_d; ra.fars = fars; ra.rays_t = ctx->rays_t;
@@ -1315,7 +1351,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     } else {
         ra.sort_slow = 0;
     }
-    if (ra.sort_slow && last_sigmas) {
+    if ((ra.sort_slow || tile_w) && last_sigmas) {
         // regrouped alive list + last-iteration tensors requested: collect per-ray records, restore the row order afterwards
         if (!ctx->dump_rec) {
             if (hipMalloc(&ctx->dump_rec, (size_t)ctx->max_rays * 8 * sizeof(float4)) != hipSuccess ||
@@ -1454,6 +1490,8 @@ int ngp_debug_disable_march_queue(int off) {
     g_lin_off = (off & 8) != 0;
     g_jump_off = (off & 1) != 0;
     g_spec_off = (off & 256) != 0;
+    g_spec_safety_x2 = ((uint32_t)off >> 9) & 15u;
+    g_tile_off = (off & 8192) != 0;
     const uint32_t sh = (uint32_t)(off >> 4) & 15u;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(d_dbg_shrink), &sh, 4);
     return NGP_OK;

@@ -232,7 +232,8 @@ class NeRFRenderer(nn.Module):
             fm = self.fused_model() if self.fused else None
             if fm is not None and not torch.is_grad_enabled():
                 weights_sum, depth, image, sigmas, rgbs = fm.render(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb,
-                                                                    want_last=self.return_last_tensors)
+                                                                    want_last=self.return_last_tensors,
+                                                                    frame_width=kwargs.get("frame_width", 0))
                 self.last_render_stats = fm.last_stats
             else:
                 weights_sum, depth, image, sigmas, rgbs = self._march_composite_loop(rays_o, rays_d, nears, fars, dt_gamma,

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3]-like check (bound 1, one cascade, cameras OUTSIDE the box at r = 3.2, SURVEY 8d "Lego"): frame time,
+samples/s and the number of rolled-back launches of the fused renderer on the procedural scene."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nerfsafetyvalidation_amd.nerf.utils import get_rays
+from nerfsafetyvalidation_amd.scene import StonehengeScene
+
+dev = torch.device("cuda:0")
+from nerfsafetyvalidation_amd import _lib
+if os.environ.get("NGP_DBG_FLAGS"):
+    _lib.lib().ngp_debug_disable_march_queue(int(os.environ["NGP_DBG_FLAGS"]))
+H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+for bound, radius in ((1, 3.2), (2, 1.5)):
+    sc = StonehengeScene(H=H, W=W, bound=bound, radius=radius)
+    model = sc.build_model(dev)
+    poses = torch.from_numpy(sc.poses).to(dev)
+    samples = rollbacks = launches = iters = 0
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        def frame(v):
+            r = get_rays(poses[v:v + 1], sc.intrinsics, H, W)
+            return model.render(r["rays_o"], r["rays_d"], staged=True, bg_color=1, perturb=False, frame_width=W)
+        for v in range(3): frame(v)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 20
+        for v in range(3, 3 + n):
+            frame(v * 7 % 200)
+            st = model.last_render_stats
+            samples += st["samples_marched"]; rollbacks += st["replayed"]; launches += st["launches"]; iters += st["iterations"]
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"bound": bound, "camera_radius": radius, "frame": f"{H}x{W}", "ms_per_frame": round(dt / n * 1e3, 3),
+                      "samples_per_s": round(samples / dt), "samples_per_frame": round(samples / n), "launches_per_frame": round(launches / n, 1), "reference_iterations_per_frame": round(iters / n, 1),
+                      "rollbacks_per_frame": round(rollbacks / n, 2)}))

@@ -174,20 +174,25 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
     N = ro.shape[0]
     outs = {}
     try:
-        for flags in (0, 1, 8, 256):     # all shortcuts / no block jump / Morton-order probes / one reference iteration per launch
-            lib.ngp_debug_disable_march_queue(flags)
+        # all shortcuts / no block jump / Morton-order probes / one reference iteration per launch / the frame-width hint (live
+        # rays listed in 4x4-pixel tiles) on top of everything
+        for flags in (0, 1, 8, 256, "tiles"):
+            lib.ngp_debug_disable_march_queue(0 if flags == "tiles" else flags)
             h = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(h.data_ptr())
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-                img = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False)["image"].float()
+                r = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False,
+                                 frame_width=sc.W if flags == "tiles" else 0)
             torch.cuda.synchronize()
-            outs[flags] = (h.clone(), img.clone(), dict(model.last_render_stats))
+            outs[flags] = (h.clone(), r["image"].float().clone(), dict(model.last_render_stats), r["sigmas"].clone(), r["rgbs"].clone())
     finally:
         lib.ngp_debug_set_sample_hash(None)
         lib.ngp_debug_disable_march_queue(0)
-    for flags in (1, 8, 256):
+    assert sc.W % 4 == 0 and N % (4 * sc.W) == 0      # (the hint is only taken for whole rows of tiles)
+    for flags in (1, 8, 256, "tiles"):
         assert torch.equal(outs[0][0], outs[flags][0]), flags
         assert torch.equal(outs[0][1], outs[flags][1]), flags
+        assert torch.equal(outs[0][3], outs[flags][3]) and torch.equal(outs[0][4], outs[flags][4]), flags   # last-iteration tensors
         for key in ("samples_marched", "samples_slots", "iterations"):
             assert outs[0][2][key] == outs[flags][2][key], (flags, key)
     assert outs[0][2]["launches"] < outs[256][2]["launches"]      # several reference iterations per launch were used
@@ -343,3 +348,31 @@ def test_fused_sample_sequence_bit_exact(setup, device, view, queue):
     # number of samples): allow 0.5 % of rays, require everything else bit-exact
     assert same.mean() > 0.995, same.mean()
     assert (want["sample_hash"] != 2166136261).mean() > 0.5       # the test is not vacuous: most rays marched something
+
+
+@pytest.mark.parametrize("max_steps", [1, 2, 8, 9, 16, 17, 40])
+def test_step_budget_ends_inside_a_multi_iteration_launch(setup, device, max_steps):
+    """`step >= max_steps` ends the reference's loop (renderer.py:347): with launches that cover up to eight iterations the end
+    falls inside one unless the launches are sized for it.  Image, schedule statistics and the LAST iteration's tensors must equal
+    those of the one-iteration-per-launch form."""
+    from nerfsafetyvalidation_amd import _lib
+    sc = setup[0]
+    model = sc.build_model(device)
+    lib = _lib.lib()
+    ro, rd = Hh.pinhole_rays(sc.poses[3], sc.intrinsics, sc.H, sc.W)
+    outs = {}
+    try:
+        for flags in (0, 256):
+            lib.ngp_debug_disable_march_queue(flags)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                r = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False, max_steps=max_steps)
+            torch.cuda.synchronize()
+            outs[flags] = (r["image"].float().clone(), r["sigmas"].clone(), r["rgbs"].clone(), dict(model.last_render_stats))
+    finally:
+        lib.ngp_debug_disable_march_queue(0)
+    a, b = outs[0], outs[256]
+    assert torch.equal(a[0], b[0])
+    assert a[1].shape == b[1].shape and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for key in ("samples_marched", "samples_slots", "iterations"):
+        assert a[3][key] == b[3][key], key
+    assert a[3]["iterations"] == min(max_steps, a[3]["iterations"])
