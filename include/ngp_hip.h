@@ -113,7 +113,7 @@ NGP_API int ngp_grid_encode_forward(const float* inputs, const void* embeddings,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                             int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
                             ngp_stream_t stream);
-/* gridencoder.cu:448-478.  grad [L,B,C]; grad_embeddings [sO,C] (accumulated into, caller zero-fills);
+/* gridencoder.cu:448-478.  grad [L,B,C]; grad_embeddings [sO,C] (accumulated into, caller zero-fills; NULL with calc_grad_inputs set = frozen table, only grad_inputs is produced);
  * grad_inputs [B,D] dtype or NULL. */
 NGP_API int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
                              const int32_t* offsets_host, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,

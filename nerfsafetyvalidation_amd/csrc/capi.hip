@@ -205,6 +205,7 @@ int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n, const f
     const uint64_t work = n > m ? n : m;
     uint32_t blocks = (uint32_t)((work + kUqThreads - 1) / kUqThreads);
     blocks = blocks < 1 ? 1 : blocks > kUqBlocks ? kUqBlocks : blocks;
+    ProfScope prof("uq_stats", s, (double)work);
     if (c_dtype == 0)
         k_uq_partial<float><<<blocks, kUqThreads, 0, s>>>((const float*)c, d, n, r, m, (double*)workspace);
     else
@@ -226,6 +227,7 @@ int ngp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     const float step_size = (float)((double)lr / bc1);
     const float sqrt_bc2 = (float)sqrt(bc2);
     const uint64_t quads = (n + 3) / 4;
+    ProfScope prof("adam_step", (hipStream_t)stream, (double)n);
     k_adam_step<<<(uint32_t)((quads + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size,
                                                                                    sqrt_bc2, 1.0f / grad_scale);
     return check_launch("adam_step");

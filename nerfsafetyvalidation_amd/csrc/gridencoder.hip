@@ -166,31 +166,99 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
     }
 }
 
-// :227-314 scatter of w * grad into the table gradient (float atomics; packed-half atomics for f16).
-template <typename T, int D, int C>
-__global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                              T* __restrict__ grad_grid, uint32_t B, uint32_t L, GridLevels lv,
-                                                              uint32_t gridtype, bool align_corners) {
-    uint32_t level, pb;
-    if (!decode_block(L, level, pb)) return;
-    const uint32_t b = pb * kGridBlock + threadIdx.x;
-    if (b >= B) return;
-    T* tab = grad_grid + (size_t)lv.offset[level] * C;
-    const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
-    const float scale = lv.scale[level];
-    const uint32_t resolution = lv.resolution[level];
-    float pos[D];
-    uint32_t pg[D];
+// :227-314 scatter of w * grad into the table gradient.
+//
+// MI355X: float atomics execute at the memory side (MI355X_MICROARCH.md "Global float atomics"): ~20 G scattered updates/s
+// chip-wide and an order of magnitude less on contended addresses -- the reference's one atomic per (point, corner) is the wrong
+// shape here.  Two changes, neither visible in the interface:
+//  * run combining: batches arrive in ray order (march_rays_train), so consecutive lanes of a wave hit the same entry at the
+//    coarse and middle levels.  A segmented scan sums every run of equal entries in fp32 and only the run's last lane issues the
+//    atomic (k_grid_backward); waves without runs skip the scan.
+//  * levels whose gradient slice fits the LDS (the first one or two dense levels, where every point of the batch lands on a few
+//    thousand entries) are accumulated per workgroup in LDS (fp32) and flushed once (k_grid_backward_small).
+// The sums are formed in fp32 and rounded once per issued atomic (the reference rounds every product to T, :303-311): closer to
+// the exact sum; like the reference's the result depends on the order of the atomics.
+template <typename T, int C>
+__device__ __forceinline__ void table_add(T* tab, uint32_t e, const float (&v)[C]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int c = 0; c < C; c++) atomicAdd(reinterpret_cast<float*>(tab) + (size_t)e * C + c, v[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+            __half2 h = __halves2half2(__float2half_rn(v[c]), __float2half_rn(v[c + 1]));
+            unsafeAtomicAdd(reinterpret_cast<__half2*>(reinterpret_cast<__half*>(tab) + (size_t)e * C + c), h);
+        }
+    }
+}
+
+// v <- sum of v over the run of equal keys that ends at this lane; returns true on the last lane of a run (invalid lanes: false)
+template <int C>
+__device__ __forceinline__ bool combine_runs(uint32_t key, bool valid, float (&v)[C]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool pvalid = __shfl_up((int)valid, 1, 64) != 0;
+    bool head = lane == 0 || !valid || !pvalid || prev != key;
+    const unsigned long long heads = __ballot(head);
+    if (heads != ~0ull) {          // at least one run of two or more lanes in this wave
+        bool f = head;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            float o[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) o[c] = __shfl_up(v[c], off, 64);
+            const bool fo = __shfl_up((int)f, off, 64) != 0;
+            if (lane >= (uint32_t)off && !f) {
+#pragma unroll
+                for (int c = 0; c < C; c++) v[c] += o[c];
+                f = fo;
+            }
+        }
+    }
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    return valid && tail;
+}
+
+template <typename T, int D>
+__device__ __forceinline__ bool locate(const float* __restrict__ inputs, uint32_t b, uint32_t B, float scale, bool align_corners, float (&pos)[D],
+                                       uint32_t (&pg)[D]) {
+    bool valid = b < B;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const float x = inputs[(size_t)b * D + d];
-        if (x < 0 || x > 1) return;
+        const float x = valid ? inputs[(size_t)b * D + d] : 0.0f;
+        valid = valid && !(x < 0 || x > 1);
         pos[d] = fmaf(x, scale, align_corners ? 0.0f : 0.5f);
         pg[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pg[d];
     }
+    return valid;
+}
+
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                              T* __restrict__ grad_grid, uint32_t B, uint32_t L, GridLevels lv,
+                                                              uint32_t gridtype, bool align_corners, uint32_t small_mask) {
+    uint32_t level, pb;
+    if (!decode_block(L, level, pb)) return;
+    if ((small_mask >> level) & 1u) return;      // k_grid_backward_small's
+    const uint32_t b = pb * kGridBlock + threadIdx.x;
+    if (pb * kGridBlock >= B) return;            // (whole blocks only: every lane of a live wave takes part in the shuffles)
+    T* tab = grad_grid + (size_t)lv.offset[level] * C;
+    const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
+    const uint32_t resolution = lv.resolution[level];
+    float pos[D];
+    uint32_t pg[D];
+    const bool valid = locate<T, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
     using V = Vec<T, C>;
-    const V g = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
+    float g[C];
+    if (valid) {
+        const V gv = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] = (float)gv.v[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] = 0.0f;
+    }
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float w = 1;
@@ -201,16 +269,75 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restric
             pl[d] = pg[d] + ((idx >> d) & 1);
         }
         const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
-        if constexpr (sizeof(T) == 4) {
+        float v[C];
 #pragma unroll
-            for (int c = 0; c < C; c++) atomicAdd(reinterpret_cast<float*>(tab) + (size_t)e * C + c, w * (float)g.v[c]);
-        } else {
+        for (int c = 0; c < C; c++) v[c] = w * g[c];
+        if (combine_runs<C>(e, valid, v)) table_add<T, C>(tab, e, v);
+    }
+}
+
+// One level whose gradient slice (entries x C floats) fits the LDS: persistent workgroups accumulate their share of the batch
+// in LDS and add the slice to the table once.  blockIdx.y = index into the list of such levels.
+constexpr int kSmallThreads = 1024;
+constexpr uint32_t kSmallMaxFloats = 30 * 1024;     // 120 KB of the 160 KB LDS
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                                       T* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
+                                                                       bool align_corners, uint32_t small_mask) {
+    extern __shared__ float acc[];
+    uint32_t level = 0, seen = 0;
+    for (uint32_t l = 0; l < (uint32_t)kMaxLevels; l++)
+        if ((small_mask >> l) & 1u) {
+            if (seen == blockIdx.y) level = l;
+            seen++;
+        }
+    T* tab = grad_grid + (size_t)lv.offset[level] * C;
+    const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
+    const uint32_t resolution = lv.resolution[level];
+    const uint32_t n = hashmap_size * C;
+    for (uint32_t i = threadIdx.x; i < n; i += kSmallThreads) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t n_pb = (B + kSmallThreads - 1) / kSmallThreads;
+    for (uint32_t pb = blockIdx.x; pb < n_pb; pb += gridDim.x) {
+        const uint32_t b = pb * kSmallThreads + threadIdx.x;
+        float pos[D];
+        uint32_t pg[D];
+        const bool valid = locate<T, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
+        using V = Vec<T, C>;
+        float g[C];
 #pragma unroll
-            for (int c = 0; c < C; c += 2) {
-                __half2 v = __halves2half2(__float2half_rn(w * (float)g.v[c]), __float2half_rn(w * (float)g.v[c + 1]));
-                unsafeAtomicAdd(reinterpret_cast<__half2*>(reinterpret_cast<__half*>(tab) + (size_t)e * C + c), v);
+        for (int c = 0; c < C; c++) g[c] = 0.0f;
+        if (valid) {
+            const V gv = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
+#pragma unroll
+            for (int c = 0; c < C; c++) g[c] = (float)gv.v[c];
+        }
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            float w = 1;
+            uint32_t pl[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+                pl[d] = pg[d] + ((idx >> d) & 1);
+            }
+            const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+            float v[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) v[c] = w * g[c];
+            if (combine_runs<C>(e, valid, v)) {
+#pragma unroll
+                for (int c = 0; c < C; c++) atomicAdd(&acc[e * C + c], v[c]);
             }
         }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < hashmap_size; e += kSmallThreads) {
+        float v[C];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < C; c++) { v[c] = acc[e * C + c]; any |= v[c] != 0.0f; }
+        if (any) table_add<T, C>(tab, e, v);
     }
 }
 
@@ -277,7 +404,34 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
                             const void* dy_dx, void* grad_inputs, uint32_t gridtype, bool ac, hipStream_t s) {
     const uint32_t nb = div_up(B, kGridBlock);
     const uint32_t LP = (L + 7) / 8;
-    k_grid_backward<T, D, C><<<nb * LP * 8, kGridBlock, 0, s>>>((const T*)grad, inputs, (T*)grad_emb, B, L, lv, gridtype, ac);
+    if (!grad_emb) {   // frozen table (the rollout's pose gradients): only the input gradient
+        if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
+        return;
+    }
+    // levels accumulated in LDS: worth it from a few thousand points per entry-kilobyte on; the slice must fit kSmallMaxFloats
+    uint32_t small_mask = 0, n_small = 0;
+    size_t lds = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t floats = (lv.offset[l + 1] - lv.offset[l]) * (uint32_t)C;
+        if (floats <= kSmallMaxFloats && (size_t)B * 8 >= (size_t)floats * 16) {
+            small_mask |= 1u << l;
+            n_small++;
+            lds = lds > floats * sizeof(float) ? lds : floats * sizeof(float);
+        }
+    }
+    if (n_small) {
+        static bool attr[4][9] = {};
+        auto kern = k_grid_backward_small<T, D, C>;
+        if (!attr[D][C]) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSmallMaxFloats * sizeof(float)));
+            attr[D][C] = true;
+        }
+        const uint32_t n_pb = div_up(B, (uint32_t)kSmallThreads);
+        const uint32_t bx = n_pb < 256u ? n_pb : 256u;
+        kern<<<dim3(bx, n_small), kSmallThreads, lds, s>>>((const T*)grad, inputs, (T*)grad_emb, B, lv, gridtype, ac, small_mask);
+    }
+    if (n_small < L)
+        k_grid_backward<T, D, C><<<nb * LP * 8, kGridBlock, 0, s>>>((const T*)grad, inputs, (T*)grad_emb, B, L, lv, gridtype, ac, small_mask);
     if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
 }
 
@@ -329,7 +483,8 @@ int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              ngp_stream_t stream) {
     (void)embeddings;
     if (B == 0) return NGP_OK;
-    NGP_REQUIRE(grad && inputs && offsets_host && grad_embeddings, "grid_encode_backward: null pointer");
+    NGP_REQUIRE(grad && inputs && offsets_host, "grid_encode_backward: null pointer");
+    NGP_REQUIRE(grad_embeddings || calc_grad_inputs, "grid_encode_backward: neither the table gradient nor the input gradient is requested");
     NGP_REQUIRE(D == 2 || D == 3, "GridEncoding: D must be 2 or 3 on this build (got %u)", D);
     NGP_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, "GridEncoding: C must be 1, 2, 4, or 8.");
     NGP_REQUIRE(L >= 1 && L <= (uint32_t)kMaxLevels, "GridEncoding: L must be in [1, %d]", kMaxLevels);

@@ -551,6 +551,7 @@ int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs,
                 "composite_rays_train_backward: null pointer");
+    ProfScope prof("composite_rays_train_backward", (hipStream_t)stream, M);
     k_composite_train_bwd<<<div_up(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
                                                                                  weights_sum, image, M, N, grad_sigmas, grad_rgbs);
     return check_launch("composite_rays_train_backward");
@@ -592,6 +593,7 @@ int ngp_get_rays(const float* poses, uint32_t Bc, float fx, float fy, float cx, 
     NGP_REQUIRE(poses && rays_o && rays_d, "get_rays: null pointer");
     NGP_REQUIRE(pixel_inds || n_pix == H * W, "get_rays: n_pix must be H*W when pixel_inds is NULL");
     dim3 grid(div_up(n_pix, kBlock), Bc);
+    ProfScope prof("get_rays", (hipStream_t)stream, (double)Bc * n_pix);
     k_get_rays<<<grid, kBlock, 0, (hipStream_t)stream>>>(poses, Bc, fx, fy, cx, cy, H, W, pixel_inds, n_pix, rays_o, rays_d);
     return check_launch("get_rays");
 }
@@ -601,6 +603,7 @@ int ngp_get_rays_backward(const float* grad_rays_o, const float* grad_rays_d, ui
     if (Bc == 0) return NGP_OK;
     NGP_REQUIRE(grad_poses, "get_rays_backward: null pointer");
     NGP_REQUIRE(pixel_inds || n_pix == H * W, "get_rays_backward: n_pix must be H*W when pixel_inds is NULL");
+    ProfScope prof("get_rays_backward", (hipStream_t)stream, (double)Bc * n_pix);
     k_get_rays_backward<<<Bc, 1024, 0, (hipStream_t)stream>>>(grad_rays_o, grad_rays_d, fx, fy, cx, cy, W, pixel_inds, n_pix, grad_poses);
     return check_launch("get_rays_backward");
 }

@@ -168,6 +168,7 @@ int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, u
     NGP_REQUIRE(grad && dy_dx && grad_inputs, "sh_encode_backward: null pointer");
     NGP_REQUIRE(D == 3, "SH encoder only support input dim == 3");
     NGP_REQUIRE(C >= 1 && C <= 8, "SH encoder only supports degree in [1, 8]");
+    ProfScope prof("sh_encode_backward", (hipStream_t)stream, B);
     k_sh_backward<<<div_up(B * D, kShBlock), kShBlock, 0, (hipStream_t)stream>>>(grad, B, D, C * C, dy_dx, grad_inputs);
     return check_launch("sh_encode_backward");
 }

@@ -62,7 +62,10 @@ class _grid_encode(Function):
         calc_grad_inputs = ctx.calc_grad_inputs
 
         grad = grad.view(B, L, C).permute(1, 0, 2).contiguous().to(embeddings.dtype)  # -> [L,B,C] (grid.py:72)
-        grad_embeddings = torch.zeros_like(embeddings)
+        # (the reference always scatters the table gradient, grid.py:74; with a frozen table autograd discards it, so it is not computed)
+        grad_embeddings = torch.zeros_like(embeddings) if ctx.needs_input_grad[1] else None
+        if grad_embeddings is None and not calc_grad_inputs:
+            return None, None, None, None, None, None, None, None
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if calc_grad_inputs else None
 
         lib = _lib.lib()

@@ -264,6 +264,52 @@ def test_grid_encode_forward_bit_exact(device, dtype, D, C):
                                    **(dict(rtol=1e-4, atol=1e-5) if dtype == np.float32 else dict(rtol=5e-2, atol=5e-2)))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_grid_encode_backward_ray_ordered_batch(device, dtype):
+    """Table gradient on a batch in ray order (consecutive points share cells at the coarse levels: the wave-level run combining)
+    and large enough for the LDS-accumulated levels, against the oracle's scatter; a frozen table gets no gradient and the input
+    gradient is unchanged by that."""
+    from nerfsafetyvalidation_amd.gridencoder import grid_encode
+    rng = np.random.default_rng(11)
+    D, C, L = 3, 2, 16
+    offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=19, desired_resolution=2048)
+    emb = rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32).astype(dtype)
+    n_rays, T = 600, 100
+    o = rng.uniform(0.3, 0.7, (n_rays, 1, 3))
+    d = rng.normal(size=(n_rays, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = (o + d * np.linspace(0, 0.35, T).reshape(1, T, 1)).reshape(-1, 3).astype(np.float32)
+    x[17] = 1.5            # out of range in the middle of a run
+    x[18] = -0.25
+    B = x.shape[0]
+    assert B * 8 >= 16 * 2 * (offsets[2] - offsets[1])      # levels 0 and 1 take the LDS path
+    g = (rng.normal(size=(B, L * C)) * 0.05).astype(np.float32).astype(dtype)
+    _, dydx = Hh.oracle_grid_encode(x, emb, offsets, pls, calc_grad=True)
+    gl = np.ascontiguousarray(g.reshape(B, L, C).transpose(1, 0, 2))
+    # reference sums in fp32 on the same (fp16-representable) values: the fp16 scatter of the reference rounds the running sum at
+    # every one of its atomics and is itself only an approximation of this
+    gi = np.zeros((B, D), np.float32)
+    ge_t = np.zeros((offsets[-1], C), np.float32)
+    O.grid_encode_backward(gl.astype(np.float32), x, emb.astype(np.float32), offsets, ge_t, B, D, C, L, float(np.log2(pls)), 16, True,
+                           dydx.astype(np.float32), gi, 0, False)
+    xt = _t(x, device).requires_grad_(True)
+    embt = _t(emb, device).requires_grad_(True)
+    grid_encode(xt, embt, _t(offsets, device), pls, 16, True, 0, False).backward(_t(g, device))
+    got = embt.grad.cpu().numpy().astype(np.float32)
+    want = ge_t.astype(np.float32)
+    scale = np.abs(want).max()
+    tol = 2e-5 * scale if dtype == np.float32 else 4e-3 * scale + 2e-3     # fp16: every issued atomic rounds the running sum to 11 bits
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), scale)
+    touched = np.abs(want).sum(-1) > 0
+    assert np.array_equal(np.abs(got).sum(-1) > 0, touched) or dtype == np.float16
+    gi_full = xt.grad.cpu().numpy().copy()
+    # frozen table
+    xt2 = _t(x, device).requires_grad_(True)
+    emb_frozen = _t(emb, device)
+    grid_encode(xt2, emb_frozen, _t(offsets, device), pls, 16, True, 0, False).backward(_t(g, device))
+    assert emb_frozen.grad is None
+    assert np.array_equal(xt2.grad.cpu().numpy(), gi_full)
+
+
 @pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_sh_encode(device, degree):
     from nerfsafetyvalidation_amd.shencoder import sh_encode
