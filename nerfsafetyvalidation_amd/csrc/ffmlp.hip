@@ -51,6 +51,25 @@ __device__ __forceinline__ half4 act_pack(uint32_t act, const f32x4& acc) {
     return h;
 }
 
+// out-of-line form for the LDS kernel (the transcendental activations are large; sinf's argument reduction needs scratch)
+__device__ __attribute__((noinline)) half4 act_pack_call(uint32_t act, f32x4 acc) { return act_pack(act, acc); }
+
+// RELU: the hidden activation is known to be ReLU at compile time; otherwise any code, out of line
+template <bool RELU>
+__device__ __forceinline__ half4 act_hidden(uint32_t act, const f32x4& acc) {
+    if constexpr (RELU) return act_pack(0u, acc);
+    else return act_pack_call(act, acc);
+}
+__device__ __forceinline__ half4 act_output(uint32_t act, const f32x4& acc) {
+    if (act > 5u) {   // none
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[r] = (_Float16)acc[r];
+        return h;
+    }
+    return act_pack_call(act, acc);
+}
+
 __device__ __forceinline__ half4 ld_half4(const _Float16* p) { return *reinterpret_cast<const half4*>(p); }
 __device__ __forceinline__ void st_half4(_Float16* p, half4 v) { *reinterpret_cast<half4*>(p) = v; }
 
@@ -118,6 +137,158 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
     }
 }
 
+// ---- LDS-resident weights, K = 32 MFMAs, R row tiles per wave pass ------------------------------------------------------
+// For in_dim % 32 == 0, hidden_dim % 32 == 0 and a weight blob that fits the LDS budget (every NeRF network of the reference).
+// The whole blob is copied once per workgroup into LDS (rows padded by 8 halves: with a stride of 4 * odd dwords the 8-byte A
+// fragment reads of a half-wave touch all 64 banks once), and each A fragment read serves R tiles of 16 batch rows.
+// v_mfma_f32_16x16x32_f16, transposed product as above: lane (c, q) holds B-fragment slot j <-> k = 32 kb + 16 (j >> 2) + 4 q +
+// (j & 3), which is exactly how two consecutive 16-row accumulator blocks (ob = 2 kb, 2 kb + 1) concatenate -- the A fragment is
+// read with the same k order (two 8-byte LDS reads), so no data is permuted anywhere.
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ half8v cat8(half4 lo, half4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+__device__ __forceinline__ half8v lds_a_frag(const _Float16* mat, uint32_t stride, uint32_t ob, uint32_t kb, uint32_t c, uint32_t q) {
+    const _Float16* p = mat + (size_t)(ob * 16 + c) * stride + kb * 32 + q * 4;
+    return cat8(*reinterpret_cast<const half4*>(p), *reinterpret_cast<const half4*>(p + 16));
+}
+
+__device__ __forceinline__ void stage_rows(_Float16* dst, const _Float16* __restrict__ src, uint32_t rows, uint32_t K) {
+    const uint32_t per_row = K / 8, n = rows * per_row;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t r = i / per_row, j = i - r * per_row;
+        *reinterpret_cast<half8v*>(dst + (size_t)r * (K + 8) + j * 8) = *reinterpret_cast<const half8v*>(src + (size_t)r * K + j * 8);
+    }
+}
+
+static size_t ffmlp_lds_halves(uint32_t in_dim, uint32_t hid, uint32_t num_layers) {
+    return (size_t)hid * (in_dim + 8) + (size_t)(num_layers - 1) * hid * (hid + 8) + (size_t)16 * (hid + 8);
+}
+
+template <int HB, int R, bool RELU>
+__global__ void __launch_bounds__(256) k_ffmlp_forward_lds(const _Float16* __restrict__ inputs, const _Float16* __restrict__ weights,
+                                                           uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t activation,
+                                                           uint32_t output_activation, _Float16* __restrict__ fwd_buf,
+                                                           _Float16* __restrict__ outputs) {
+    extern __shared__ _Float16 wl[];
+    constexpr uint32_t HID = HB * 16, KB = HB / 2, HS = HID + 8;
+    const uint32_t IS = in_dim + 8, IKB = in_dim >> 5;
+    // ---- weights -> LDS (layout: [HID][in_dim+8] | (num_layers-1) x [HID][HID+8] | [16][HID+8])
+    stage_rows(wl, weights, HID, in_dim);
+    _Float16* wl_hidden = wl + (size_t)HID * IS;
+    for (uint32_t k = 0; k + 1 < num_layers; k++)
+        stage_rows(wl_hidden + (size_t)k * HID * HS, weights + (size_t)HID * in_dim + (size_t)k * HID * HID, HID, HID);
+    _Float16* wl_out = wl_hidden + (size_t)(num_layers - 1) * HID * HS;
+    stage_rows(wl_out, weights + (size_t)HID * in_dim + (size_t)(num_layers - 1) * HID * HID, 16, HID);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_tiles = B >> 4, n_groups = (n_tiles + R - 1) / R;
+    for (uint32_t grp = wave; grp < n_groups; grp += n_waves) {
+        f32x4 acc[R][HB];
+        half8v h[R][KB];
+        uint32_t row[R];
+        bool live[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            live[t] = grp * R + t < n_tiles;          // wave-uniform: tiles are whole
+            row[t] = (grp * R + t) * 16 + c;
+#pragma unroll
+            for (int ob = 0; ob < HB; ob++) acc[t][ob] = (f32x4){0, 0, 0, 0};
+        }
+        // ---- input layer
+        for (uint32_t kb = 0; kb < IKB; kb++) {
+            half8v xb[R];
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+                const _Float16* p = inputs + (size_t)row[t] * in_dim + kb * 32 + q * 4;
+                xb[t] = live[t] ? cat8(ld_half4(p), ld_half4(p + 16)) : (half8v){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int ob = 0; ob < HB; ob++) {
+                const half8v a = lds_a_frag(wl, IS, ob, kb, c, q);
+#pragma unroll
+                for (int t = 0; t < R; t++) acc[t][ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[t], acc[t][ob], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+#pragma unroll
+            for (int kb = 0; kb < (int)KB; kb++) {
+                const half4 lo = act_hidden<RELU>(activation, acc[t][2 * kb]), hi = act_hidden<RELU>(activation, acc[t][2 * kb + 1]);
+                h[t][kb] = cat8(lo, hi);
+                if (fwd_buf && live[t]) {
+                    st_half4(fwd_buf + (size_t)row[t] * HID + (2 * kb) * 16 + q * 4, lo);
+                    st_half4(fwd_buf + (size_t)row[t] * HID + (2 * kb + 1) * 16 + q * 4, hi);
+                }
+            }
+        }
+        // ---- hidden layers
+        for (uint32_t k = 0; k + 1 < num_layers; k++) {
+            const _Float16* W = wl_hidden + (size_t)k * HID * HS;
+#pragma unroll
+            for (int t = 0; t < R; t++)
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) acc[t][ob] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < (int)KB; kb++) {
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) {
+                    const half8v a = lds_a_frag(W, HS, ob, kb, c, q);
+#pragma unroll
+                    for (int t = 0; t < R; t++) acc[t][ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, h[t][kb], acc[t][ob], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+#pragma unroll
+                for (int kb = 0; kb < (int)KB; kb++) {
+                    const half4 lo = act_hidden<RELU>(activation, acc[t][2 * kb]), hi = act_hidden<RELU>(activation, acc[t][2 * kb + 1]);
+                    h[t][kb] = cat8(lo, hi);
+                    if (fwd_buf && live[t]) {
+                        _Float16* dst = fwd_buf + ((size_t)(k + 1) * B + row[t]) * HID + q * 4;
+                        st_half4(dst + (2 * kb) * 16, lo);
+                        st_half4(dst + (2 * kb + 1) * 16, hi);
+                    }
+                }
+            }
+        }
+        // ---- output layer (16 padded outputs)
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            f32x4 o = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < (int)KB; kb++) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_a_frag(wl_out, HS, 0, kb, c, q), h[t][kb], o, 0, 0, 0);
+            if (live[t]) st_half4(outputs + (size_t)row[t] * 16 + q * 4, act_output(output_activation, o));
+        }
+    }
+}
+
+constexpr size_t kFfmlpLdsMax = 64 * 1024;   // two workgroups per CU
+
+template <int HB, int R>
+static void launch_ffmlp_lds(const uint16_t* in, const uint16_t* w, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
+                             uint32_t out_act, uint16_t* fwd, uint16_t* out, hipStream_t s) {
+    const size_t lds = ffmlp_lds_halves(in_dim, HB * 16, num_layers) * sizeof(_Float16);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_ffmlp_forward_lds<HB, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfmlpLdsMax);
+        (void)hipFuncSetAttribute((const void*)k_ffmlp_forward_lds<HB, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfmlpLdsMax);
+        attr = true;
+    }
+    const uint32_t n_groups = div_up(B / 16, (uint32_t)R);
+    uint32_t blocks = div_up(n_groups, 4);
+    if (blocks > 256 * 2) blocks = 256 * 2;   // two resident workgroups per CU, grid-stride beyond that
+    if (act == 0)
+        k_ffmlp_forward_lds<HB, R, true><<<blocks, 256, lds, s>>>((const _Float16*)in, (const _Float16*)w, B, in_dim, num_layers, act, out_act,
+                                                                   (_Float16*)fwd, (_Float16*)out);
+    else
+        k_ffmlp_forward_lds<HB, R, false><<<blocks, 256, lds, s>>>((const _Float16*)in, (const _Float16*)w, B, in_dim, num_layers, act, out_act,
+                                                                    (_Float16*)fwd, (_Float16*)out);
+}
+
 template <int HB>
 static void launch_ffmlp(const uint16_t* in, const uint16_t* w, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                          uint32_t out_act, uint16_t* fwd, uint16_t* out, hipStream_t s) {
@@ -138,6 +309,15 @@ static int ffmlp_run(const uint16_t* inputs, const uint16_t* weights, uint32_t B
     NGP_REQUIRE(output_dim == 16, "FFMLP current only supports (padded) output dim == 16, but got %u", output_dim);
     NGP_REQUIRE(num_layers >= 2, "FFMLP num_layers should be larger than 2 (3 matmuls), but got %u", num_layers);
     ProfScope prof("ffmlp_forward", s, B);
+    if ((hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128) && input_dim % 32 == 0 &&
+        ffmlp_lds_halves(input_dim, hidden_dim, num_layers) * sizeof(_Float16) <= kFfmlpLdsMax) {
+        switch (hidden_dim) {
+            case 32: launch_ffmlp_lds<2, 4>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
+            case 64: launch_ffmlp_lds<4, 4>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
+            default: launch_ffmlp_lds<8, 2>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
+        }
+        return check_launch(what);
+    }
     switch (hidden_dim) {
         case 16: launch_ffmlp<1>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
         case 32: launch_ffmlp<2>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;

@@ -73,11 +73,15 @@ line("near_far_from_aabb", "near_far_from_aabb", N, "rays", 32 * N)
 line("march_rays_train (two passes + ray-order offsets)", "march_rays_train", M, "samples", 32 * M + (24 + 8 + 12) * N)
 line("grid_encode_forward f16 (training batch: samples in ray order)", "grid_encode_forward", Mp, "points", 588 * Mp)
 line("sh_encode_forward deg 4", "sh_encode_forward", Mp, "points", 76 * Mp)
-line("ffmlp_forward (sigma 32-64-64-16 and colour 32-64-64-64-16, averaged)", "ffmlp_forward", Mp, "rows", (64 + 32) * Mp,
-     flops_per_call=(14336 + 22528) / 2 * Mp, note="training forward also stores the hidden activations (2 or 3 x 128 B per row)")
+line("ffmlp_forward, training (sigma 32-64-64-16 and colour 32-64-64-64-16, averaged)", "ffmlp_forward", Mp, "rows",
+     (64 + 32 + 2.5 * 128) * Mp, flops_per_call=(14336 + 22528) / 2 * Mp,
+     note="bytes: 64 in + 32 out + the stored hidden activations (2 or 3 x 128 B per row) that the backward pass reads")
 line("composite_rays_train_forward", "composite_rays_train_forward", M, "samples", 24 * M + (12 + 20) * N)
 line("composite_rays_train_backward", "composite_rays_train_backward", M, "samples", (24 + 16) * M + (12 + 4 + 12 + 4 + 12) * N)
-line("ffmlp_backward (both nets, averaged)", "ffmlp_backward", Mp, "rows", (64 + 32 + 32 + 64) * Mp, flops_per_call=2 * (14336 + 22528) / 2 * Mp)
+line("ffmlp_backward (both nets, averaged: activation chain + split-K weight gradients)", "ffmlp_backward", Mp, "rows",
+     (32 + 64 + 2.5 * 128 * 2 + 64 + 2.5 * 128 * 2 + 32) * Mp, flops_per_call=2 * (14336 + 22528) / 2 * Mp,
+     note="bytes: chain reads grad 32 + stored activations, writes activation gradients + input gradient 64; weight-gradient pass reads "
+          "inputs 64, activations and activation gradients again, grad 32")
 line("sh_encode_backward", "sh_encode_backward", Mp, "points", (64 + 192 + 12) * Mp)
 line("grid_encode_backward f16 (table gradient, packed-half atomics)", "grid_encode_backward", Mp, "points", 588 * Mp)
 line("adam_step (all parameters, averaged over the 3 tensors)", "adam_step", n_param / 3, "params", 28 * n_param / 3)
