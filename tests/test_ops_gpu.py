@@ -465,3 +465,39 @@ def test_get_rays(device):
     rnd = get_rays(poses, sc.intrinsics, sc.H, sc.W, N=100)
     assert rnd["rays_d"].shape == (3, 100, 3) and rnd["inds"].shape == (3, 100)
     assert torch.equal(rnd["rays_d"][1], out["rays_d"][1][rnd["inds"][1]])
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_grid_encode_full_size_properties(device, dtype):
+    """The `run` path's chunk size (B = 2,097,152 points, 16 levels, T = 2^19), checked through properties instead of
+    the oracle on every point: linearity in the table (a table scaled by 2 doubles every output -- exactly in fp32, where powers of two commute
+    with every rounding), permutation equivariance in the points, zeros for out-of-range points, and a 4096-point sample
+    bit-exact against the oracle."""
+    from nerfsafetyvalidation_amd.gridencoder import grid_encode
+    rng = np.random.default_rng(23)
+    D, C, L, B = 3, 2, 16, 2097152
+    offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=19, desired_resolution=4096)
+    emb = rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32).astype(dtype)
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[5] = 1.25
+    xt, et, ot = _t(x, device), _t(emb, device), _t(offsets, device)
+    out = grid_encode(xt, et, ot, pls, 16, False, 0, False)
+    assert out.shape == (B, L * C)
+    out2 = grid_encode(xt, et * 2, ot, pls, 16, False, 0, False)
+    if dtype == np.float32:
+        assert torch.equal(out2, out * 2)
+    else:
+        # fp16 rounds every corner product to half (c10::Half semantics): products in the subnormal range (tiny trilinear weights)
+        # do not scale exactly, and such a difference can move the running sum by one ulp
+        d = (out2.float() - 2 * out.float()).abs()
+        assert d.max().item() <= 2.0 ** -9      # two ulps of the largest partial sum (|doubled values| <= 1)
+        assert (d == 0).float().mean().item() > 0.99
+    perm = torch.randperm(B, device=device)
+    outp = grid_encode(xt[perm].contiguous(), et, ot, pls, 16, False, 0, False)
+    assert torch.equal(outp, out[perm])
+    assert torch.all(out[5] == 0)
+    sel = rng.choice(B, 4096, replace=False)
+    want, _ = Hh.oracle_grid_encode(x[sel], emb, offsets, pls)
+    got = out[torch.from_numpy(sel).to(device)].cpu().numpy()
+    bits = np.uint32 if dtype == np.float32 else np.uint16
+    assert np.array_equal(got.view(bits), want.view(bits))
