@@ -120,6 +120,10 @@ NGP_API int ngp_grid_encode_backward(const void* grad, const float* inputs, cons
                              uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
                              void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream);
 
+/* The table gradient of large fp16 batches goes through a device workspace that ngp_grid_encode_backward grows on demand and
+ * keeps (one per device; calls on different streams of one device must not overlap).  This frees it. */
+NGP_API int ngp_grid_encode_release_workspace(void);
+
 /* ---------------- _shencoder (shencoder/src/shencoder.h:10-13) ---------------- */
 
 /* shencoder.cu:402-420.  inputs f32 [B,3]; outputs f32 [B,C*C]; dy_dx f32 [B,3*C*C] or NULL; C = degree 1..8 */

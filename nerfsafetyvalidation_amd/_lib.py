@@ -58,6 +58,7 @@ SIGNATURES = {
     "ngp_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int, _int, _vp],
     "ngp_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _u32, _int,
                                  _int, _vp],
+    "ngp_grid_encode_release_workspace": [],
     "ngp_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _int, _vp, _vp],
     "ngp_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     "ngp_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],

@@ -16,6 +16,10 @@
 #include <hip/hip_fp16.h>
 #include <math.h>
 
+#include <stdlib.h>
+
+#include <mutex>
+
 #include "ngp_common.hpp"
 
 namespace ngp {
@@ -178,6 +182,10 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
 //    thousand entries) are accumulated per workgroup in LDS (fp32) and flushed once (k_grid_backward_small).
 // The sums are formed in fp32 and rounded once per issued atomic (the reference rounds every product to T, :303-311): closer to
 // the exact sum; like the reference's the result depends on the order of the atomics.
+struct BinLevels {    // a list of levels handed to a kernel by value
+    uint32_t level[kMaxLevels];
+};
+
 template <typename T, int C>
 __device__ __forceinline__ void table_add(T* tab, uint32_t e, const float (&v)[C]) {
     if constexpr (sizeof(T) == 4) {
@@ -237,10 +245,10 @@ __device__ __forceinline__ bool locate(const float* __restrict__ inputs, uint32_
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                               T* __restrict__ grad_grid, uint32_t B, uint32_t L, GridLevels lv,
-                                                              uint32_t gridtype, bool align_corners, uint32_t small_mask) {
-    uint32_t level, pb;
-    if (!decode_block(L, level, pb)) return;
-    if ((small_mask >> level) & 1u) return;      // k_grid_backward_small's
+                                                              uint32_t gridtype, bool align_corners, BinLevels rest, uint32_t n_rest) {
+    // the levels left to this kernel (not LDS-accumulated, not binned), dealt round-robin over the workgroups: atomics execute at
+    // the memory side, so there is no L2 affinity to keep and every XCD works on every level
+    const uint32_t level = rest.level[blockIdx.x % n_rest], pb = blockIdx.x / n_rest;
     const uint32_t b = pb * kGridBlock + threadIdx.x;
     if (pb * kGridBlock >= B) return;            // (whole blocks only: every lane of a live wave takes part in the shuffles)
     T* tab = grad_grid + (size_t)lv.offset[level] * C;
@@ -341,6 +349,176 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
     }
 }
 
+// ---- binned scatter for the hashed levels (fp16 table, C = 2) ------------------------------------------------------------
+// A hashed level spreads a batch's updates uniformly over its 2^19 entries: no two lanes agree, every update is its own
+// scattered atomic (~17 G/s chip-wide, the memory-side atomic unit handles one 64-byte request per update).  Two streaming
+// passes replace them:
+//  1. k_grid_bwd_bin: a workgroup of 1024 points computes its 8192 updates and sorts them in LDS into bins of 4096 consecutive
+//     entries (fixed capacity per bin, 1.5 x the mean; the rare overflow falls back to the atomic), then writes each bin's
+//     records (entry-in-bin, two fp16 values: 8 bytes) to its own segment of a workspace -- contiguous runs, plain stores;
+//  2. k_grid_bwd_bin_reduce: the workgroups that own a bin read its segments, accumulate in LDS (fp32) and add the 4096-entry
+//     slice to the table with coalesced atomics (256 contiguous bytes per wave instruction: the full atomic rate).
+constexpr uint32_t kBinLog = 12, kBinEntries = 1u << kBinLog;    // entries per bin
+constexpr uint32_t kBinMax = 128;                                // bins per level (levels of at most 2^19 entries)
+constexpr uint32_t kBinCap = 96;                                 // records per (point block, bin)
+constexpr uint32_t kBinPoints = 1024;                            // points per k_grid_bwd_bin workgroup (one per thread)
+constexpr uint32_t kBinSplit = 8;                                // reducing workgroups per bin
+// entry -> (bin, slot in the bin).  Hashed levels: bins of 4096 consecutive entries (the hash spreads any batch evenly, and the
+// slice goes back to the table in contiguous atomics).  Dense levels: entries dealt round-robin over 128 bins, so that the
+// spatially clustered updates of a ray bundle still fill the bins evenly (the slice goes back with scattered atomics -- few,
+// the tables are small).
+__device__ __forceinline__ uint32_t bin_of(uint32_t e, bool hashed) { return hashed ? e >> kBinLog : e & (kBinMax - 1); }
+__device__ __forceinline__ uint32_t slot_of(uint32_t e, bool hashed) { return hashed ? e & (kBinEntries - 1) : e >> 7; }
+__device__ __forceinline__ uint32_t entry_of(uint32_t bin, uint32_t slot, bool hashed) { return hashed ? (bin << kBinLog) + slot : (slot << 7) + bin; }
+static_assert(kBinMax == 128, "slot_of / entry_of assume 128 bins");
+template <int D>
+__global__ void __launch_bounds__(kBinPoints) k_grid_bwd_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs,
+                                                             _Float16* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
+                                                             bool align_corners, BinLevels bl, uint32_t first, uint2* __restrict__ records,
+                                                             uint32_t* __restrict__ counts) {
+    constexpr int C = 2;
+    extern __shared__ uint2 rec[];                       // [kBinMax][kBinCap]
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(rec + kBinMax * kBinCap);
+    const uint32_t level = bl.level[first + blockIdx.y];
+    _Float16* tab = grad_grid + (size_t)lv.offset[level] * C;
+    const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
+    const uint32_t resolution = lv.resolution[level];
+    const bool hashed = lv.hashed[level] != 0;
+    const uint32_t n_bins = hashed ? (hashmap_size + kBinEntries - 1) >> kBinLog : kBinMax;
+    if (threadIdx.x < kBinMax) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x * kBinPoints + threadIdx.x;
+    float pos[D];
+    uint32_t pg[D];
+    const bool valid = locate<_Float16, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
+    float g[C] = {0.0f, 0.0f};
+    if (valid) {
+        const Vec<_Float16, C> gv = *reinterpret_cast<const Vec<_Float16, C>*>(grad + ((size_t)level * B + b) * C);
+        g[0] = (float)gv.v[0]; g[1] = (float)gv.v[1];
+    }
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float w = 1;
+        uint32_t pl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+            pl[d] = pg[d] + ((idx >> d) & 1);
+        }
+        const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+        float v[C] = {w * g[0], w * g[1]};
+        if (combine_runs<C>(e, valid, v)) {
+            const uint32_t bin = bin_of(e, hashed);
+            const uint32_t r = atomicAdd(&cnt[bin], 1u);
+            if (r < kBinCap) {
+                const __half2 h = __halves2half2(__float2half_rn(v[0]), __float2half_rn(v[1]));
+                rec[bin * kBinCap + r] = make_uint2(slot_of(e, hashed), *reinterpret_cast<const uint32_t*>(&h));
+            } else {
+                table_add<_Float16, C>(tab, e, v);       // bin full: straight to the table
+            }
+        }
+    }
+    __syncthreads();
+    const size_t seg = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBinMax;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t bin = wave; bin < n_bins; bin += kBinPoints / 64) {
+        const uint32_t c = cnt[bin] < kBinCap ? cnt[bin] : kBinCap;
+        uint2* dst = records + (seg + bin) * kBinCap;
+        for (uint32_t r = lane; r < c; r += 64) dst[r] = rec[bin * kBinCap + r];
+        if (lane == 0) counts[seg + bin] = c;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_grid_bwd_bin_reduce(const uint2* __restrict__ records, const uint32_t* __restrict__ counts,
+                                                             _Float16* __restrict__ grad_grid, GridLevels lv, BinLevels bl, uint32_t first,
+                                                             uint32_t n_pblocks) {
+    __shared__ float acc[kBinEntries * 2];
+    const uint32_t level = bl.level[first + blockIdx.y];
+    const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
+    const bool hashed = lv.hashed[level] != 0;
+    const uint32_t n_bins = hashed ? (hashmap_size + kBinEntries - 1) >> kBinLog : kBinMax;
+    const uint32_t bin = blockIdx.x / kBinSplit, split = blockIdx.x % kBinSplit;
+    if (bin >= n_bins) return;
+    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += 256) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // each wave walks its share of the point blocks, four segments in flight; a segment's records are loaded without waiting for
+    // its count (slots past the count hold stale bytes and are masked)
+    constexpr uint32_t U = 4, stride = kBinSplit * 4;
+    for (uint32_t blk0 = split * 4 + wave; blk0 < n_pblocks; blk0 += stride * U) {
+        uint32_t c[U];
+        uint2 u0[U];
+        const uint2* src[U];
+#pragma unroll
+        for (uint32_t k = 0; k < U; k++) {
+            const uint32_t blk = blk0 + k * stride;
+            const bool on = blk < n_pblocks;
+            const size_t seg = ((size_t)blockIdx.y * n_pblocks + (on ? blk : 0)) * kBinMax + bin;
+            c[k] = on ? counts[seg] : 0u;
+            src[k] = records + seg * kBinCap;
+            u0[k] = src[k][lane];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < U; k++) {
+            if (lane < c[k]) {
+                const __half2 h = *reinterpret_cast<const __half2*>(&u0[k].y);
+                atomicAdd(&acc[u0[k].x * 2], __low2float(h));
+                atomicAdd(&acc[u0[k].x * 2 + 1], __high2float(h));
+            }
+            if (lane + 64 < c[k]) {      // the segment's tail (only the fuller half of the segments have one)
+                const uint2 u1 = src[k][lane + 64];
+                const __half2 h = *reinterpret_cast<const __half2*>(&u1.y);
+                atomicAdd(&acc[u1.x * 2], __low2float(h));
+                atomicAdd(&acc[u1.x * 2 + 1], __high2float(h));
+            }
+        }
+    }
+    __syncthreads();
+    _Float16* tab = grad_grid + (size_t)lv.offset[level] * 2;
+    for (uint32_t i = threadIdx.x; i < kBinEntries; i += 256) {
+        const uint32_t e = entry_of(bin, i, hashed);
+        const float v[2] = {acc[i * 2], acc[i * 2 + 1]};
+        if (e < hashmap_size && (v[0] != 0.0f || v[1] != 0.0f)) table_add<_Float16, 2>(tab, e, v);
+    }
+}
+
+// workspace of the binned scatter: grown on demand, one per device, reused by every call (calls on different streams of one
+// device must not overlap; ngp_grid_encode_release_workspace frees it)
+static std::mutex g_bin_mu;
+static void* g_bin_ws[32] = {};
+static size_t g_bin_bytes[32] = {};
+static void* bin_workspace(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    std::lock_guard<std::mutex> lk(g_bin_mu);
+    if (g_bin_bytes[dev] < bytes) {
+        if (g_bin_ws[dev]) (void)hipFree(g_bin_ws[dev]);   // hipFree waits for work that still uses it
+        g_bin_ws[dev] = nullptr;
+        g_bin_bytes[dev] = 0;
+        if (hipMalloc(&g_bin_ws[dev], bytes) != hipSuccess) return nullptr;
+        g_bin_bytes[dev] = bytes;
+    }
+    return g_bin_ws[dev];
+}
+static void bin_release() {
+    std::lock_guard<std::mutex> lk(g_bin_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < 32; d++)
+        if (g_bin_ws[d]) {
+            (void)hipSetDevice(d);
+            (void)hipFree(g_bin_ws[d]);
+            g_bin_ws[d] = nullptr;
+            g_bin_bytes[d] = 0;
+        }
+    (void)hipSetDevice(cur);
+}
+constexpr size_t kBinWorkspaceMax = (size_t)4 << 30;    // levels are processed in groups that fit this
+static bool bin_off() {                                  // diagnostics (NGP_GRID_NO_BINS set): atomics for every level
+    static const bool off = getenv("NGP_GRID_NO_BINS") != nullptr;
+    return off;
+}
+
 // :317-343
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx,
@@ -403,7 +581,6 @@ template <typename T, int D, int C>
 static void launch_backward(const void* grad, const float* inputs, void* grad_emb, uint32_t B, uint32_t L, const GridLevels& lv, bool gi,
                             const void* dy_dx, void* grad_inputs, uint32_t gridtype, bool ac, hipStream_t s) {
     const uint32_t nb = div_up(B, kGridBlock);
-    const uint32_t LP = (L + 7) / 8;
     if (!grad_emb) {   // frozen table (the rollout's pose gradients): only the input gradient
         if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
         return;
@@ -430,8 +607,45 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         const uint32_t bx = n_pb < 256u ? n_pb : 256u;
         kern<<<dim3(bx, n_small), kSmallThreads, lds, s>>>((const T*)grad, inputs, (T*)grad_emb, B, lv, gridtype, ac, small_mask);
     }
-    if (n_small < L)
-        k_grid_backward<T, D, C><<<nb * LP * 8, kGridBlock, 0, s>>>((const T*)grad, inputs, (T*)grad_emb, B, L, lv, gridtype, ac, small_mask);
+    // hashed levels of an fp16, two-feature table: binned two-pass scatter instead of one scattered atomic per update
+    uint32_t done_mask = small_mask, n_done = n_small;
+    if constexpr (sizeof(T) == 2 && C == 2) {
+        BinLevels bl = {};
+        uint32_t n_bin = 0;
+        if (!bin_off() && B >= 128u * 1024u)
+            for (uint32_t l = 0; l < L; l++)
+                if (!((small_mask >> l) & 1u) && lv.offset[l + 1] - lv.offset[l] <= kBinMax * kBinEntries) bl.level[n_bin++] = l;
+        const uint32_t n_pb = div_up(B, kBinPoints);
+        const size_t per_level = (size_t)n_pb * kBinMax * (kBinCap * sizeof(uint2) + sizeof(uint32_t));
+        uint32_t group = n_bin ? (uint32_t)(kBinWorkspaceMax / per_level) : 0;
+        group = group < n_bin ? group : n_bin;
+        char* ws = group ? (char*)bin_workspace(per_level * group) : nullptr;
+        if (ws) {
+            static bool attr = false;
+            const size_t lds_bin = (size_t)kBinMax * kBinCap * sizeof(uint2) + kBinMax * sizeof(uint32_t);
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void*)k_grid_bwd_bin<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin);
+                attr = true;
+            }
+            uint2* records = reinterpret_cast<uint2*>(ws);
+            uint32_t* counts = reinterpret_cast<uint32_t*>(ws + (size_t)group * n_pb * kBinMax * kBinCap * sizeof(uint2));
+            for (uint32_t first = 0; first < n_bin; first += group) {
+                const uint32_t n = n_bin - first < group ? n_bin - first : group;
+                k_grid_bwd_bin<D><<<dim3(n_pb, n), kBinPoints, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype, ac, bl,
+                                                                              first, records, counts);
+                k_grid_bwd_bin_reduce<<<dim3(kBinMax * kBinSplit, n), 256, 0, s>>>(records, counts, (_Float16*)grad_emb, lv, bl, first, n_pb);
+            }
+            for (uint32_t i = 0; i < n_bin; i++) done_mask |= 1u << bl.level[i];
+            n_done += n_bin;
+        }
+    }
+    if (n_done < L) {
+        BinLevels rest = {};
+        uint32_t n_rest = 0;
+        for (uint32_t l = 0; l < L; l++)
+            if (!((done_mask >> l) & 1u)) rest.level[n_rest++] = l;
+        k_grid_backward<T, D, C><<<nb * n_rest, kGridBlock, 0, s>>>((const T*)grad, inputs, (T*)grad_emb, B, L, lv, gridtype, ac, rest, n_rest);
+    }
     if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
 }
 
@@ -510,6 +724,11 @@ int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* 
         }
     }
     return check_launch("grid_encode_backward");
+}
+
+int ngp_grid_encode_release_workspace(void) {
+    bin_release();
+    return NGP_OK;
 }
 
 }  // extern "C"

@@ -264,8 +264,8 @@ def test_grid_encode_forward_bit_exact(device, dtype, D, C):
                                    **(dict(rtol=1e-4, atol=1e-5) if dtype == np.float32 else dict(rtol=5e-2, atol=5e-2)))
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.float16])
-def test_grid_encode_backward_ray_ordered_batch(device, dtype):
+@pytest.mark.parametrize("dtype,n_rays,T", [(np.float32, 600, 100), (np.float16, 600, 100), (np.float16, 600, 260), (np.float16, 160000, 1)])
+def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T):
     """Table gradient on a batch in ray order (consecutive points share cells at the coarse levels: the wave-level run combining)
     and large enough for the LDS-accumulated levels, against the oracle's scatter; a frozen table gets no gradient and the input
     gradient is unchanged by that."""
@@ -274,7 +274,8 @@ def test_grid_encode_backward_ray_ordered_batch(device, dtype):
     D, C, L = 3, 2, 16
     offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=19, desired_resolution=2048)
     emb = rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32).astype(dtype)
-    n_rays, T = 600, 100
+    # (600 x 260 and 160000 x 1 points: above 128 k points the hashed levels of an fp16 table take the binned two-pass scatter;
+    #  T = 1 gives unrelated points, i.e. no runs at all)
     o = rng.uniform(0.3, 0.7, (n_rays, 1, 3))
     d = rng.normal(size=(n_rays, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
     x = (o + d * np.linspace(0, 0.35, T).reshape(1, T, 1)).reshape(-1, 3).astype(np.float32)
@@ -297,7 +298,7 @@ def test_grid_encode_backward_ray_ordered_batch(device, dtype):
     got = embt.grad.cpu().numpy().astype(np.float32)
     want = ge_t.astype(np.float32)
     scale = np.abs(want).max()
-    tol = 2e-5 * scale if dtype == np.float32 else 4e-3 * scale + 2e-3     # fp16: every issued atomic rounds the running sum to 11 bits
+    tol = 2e-5 * scale if dtype == np.float32 else 8e-3 * scale + 2e-3     # fp16: every issued atomic rounds the running sum to 11 bits
     assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), scale)
     touched = np.abs(want).sum(-1) > 0
     assert np.array_equal(np.abs(got).sum(-1) > 0, touched) or dtype == np.float16
