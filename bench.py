@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the flow)")
+    p.add_argument("--batched-views", type=int, default=4, help="extra, untimed leg: cameras per render call (0 = skip); reported under 'batched'")
     p.add_argument("--no-last", action="store_true", help="do not materialise the last iteration's sigmas/rgbs tensors")
     return p.parse_args()
 
@@ -159,6 +160,26 @@ def main():
                         "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
                         "algorithmic_bytes_per_sample": TABLE_BYTES_PER_SAMPLE, "algorithmic_bytes_per_ray_iteration": RAY_BYTES_PER_RAY_ITER}
 
+    # ---- extra leg (rank 0, N = 1, not part of `value`): several cameras per render call, as a camera sweep may hand them over
+    batched = None
+    if rank == 0 and world == 1 and args.batched_views > 1:
+        nv = args.batched_views
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            def call(i):
+                v = (i * nv) % (n_views - nv)
+                r = get_rays(poses[v:v + nv], intr, H, W)
+                model.render(r["rays_o"], r["rays_d"], staged=True, bg_color=1, perturb=False, frame_width=W)
+                return model.last_render_stats["samples_marched"]
+            call(0)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            n_calls = max(2, 16 // nv)
+            sb = sum(call(1 + i) for i in range(n_calls))
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+        batched = {"views_per_call": nv, "samples_per_s": round(sb / tb, 1), "frames_per_s": round(n_calls * nv / tb, 2),
+                   "note": "same renderer, rays of several 800x800 cameras in one render call (rays [B, H*W, 3]); not part of `value`"}
+
     tot = torch.tensor([float(samples), float(iters), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone()
@@ -210,6 +231,7 @@ def main():
             "loop_iterations_per_frame": round(float(tot[1]) / frames, 1),
             "roofline": roof,
             "cpu_baseline": cpu,
+            "batched": batched,
         }
         print(json.dumps(line))
     if world > 1:
