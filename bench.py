@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the flow)")
+    p.add_argument("--in-flight", type=int, default=2, help="frames rendered concurrently per GPU, each by its own render call on its own stream "
+                                                           "(nerfsafetyvalidation_amd.pipeline.FramePipeline); 1 = strictly one after the other")
     p.add_argument("--batched-views", type=int, default=4, help="extra, untimed leg: cameras per render call (0 = skip); reported under 'batched'")
     p.add_argument("--no-last", action="store_true", help="do not materialise the last iteration's sigmas/rgbs tensors")
     return p.parse_args()
@@ -66,6 +68,7 @@ def main():
     from nerfsafetyvalidation_amd import _lib
     from nerfsafetyvalidation_amd.dist import gather_views_start
     from nerfsafetyvalidation_amd.nerf.utils import get_rays
+    from nerfsafetyvalidation_amd.pipeline import FramePipeline
     from nerfsafetyvalidation_amd.scene import StonehengeScene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,20 +103,46 @@ def main():
 
     pending = []
 
-    def render_step(step, exchange=True):
+    def render_frame(step):
+        """one frame = one drop-in render call; returns (tile to exchange or None, (samples, iterations, slots))"""
         v = view_of(step)
         rays = get_rays(poses[v:v + 1], intr, H, W)
         # frame_width: scheduling hint of this build (ngp_render_ctx_set_frame_width); the rendered values do not depend on it
         out = model.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False, frame_width=W)
         st = model.last_render_stats
-        if world > 1 and exchange:
-            # the path's one exchange step: all-gather the rendered tile (rgb + depth in one tensor, one collective).  It runs on
-            # the backend's stream while the next view renders; the previous step's gather is completed first.
-            tile = torch.cat([out["image"], out["depth"].unsqueeze(-1)], -1)
-            if pending:
-                pending.pop().finish()
-            pending.append(gather_views_start(tile, world))
-        return st["samples_marched"], st["iterations"], st["samples_slots"]
+        tile = torch.cat([out["image"], out["depth"].unsqueeze(-1)], -1) if world > 1 else None
+        return tile, (st["samples_marched"], st["iterations"], st["samples_slots"])
+
+    def exchange(tile):
+        # the path's one exchange step: all-gather the rendered tile (rgb + depth in one tensor, one collective).  It runs on the
+        # backend's stream while the next views render; the previous step's gather is completed first.
+        if pending:
+            pending.pop().finish()
+        pending.append(gather_views_start(tile, world))
+
+    def render_steps(first, count, pipe):
+        """`count` frames starting at step `first`: `in_flight` of them at a time, collectives issued by this thread in step order"""
+        tot = [0, 0, 0]
+        if pipe is None:
+            results = (render_frame(first + i) for i in range(count))
+            for tile, c in results:
+                if tile is not None:
+                    exchange(tile)
+                tot = [a + b for a, b in zip(tot, c)]
+            return tot
+        futures = [pipe.submit_fn(render_frame, first + i) for i in range(count)]
+        for f in futures:
+            (tile, c), _, done = f.result()
+            if tile is not None:
+                cur = torch.cuda.current_stream()
+                cur.wait_event(done)
+                tile.record_stream(cur)
+                exchange(tile)
+            tot = [a + b for a, b in zip(tot, c)]
+        return tot
+
+    def render_step(step, exchange=True):   # (roofline leg: one frame, this thread, no collective)
+        return render_frame(step)[1]
 
     def barrier():
         while pending:
@@ -122,19 +151,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pipe = FramePipeline(model, in_flight=args.in_flight, device=dev) if args.in_flight > 1 else None
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        for i in range(args.warmup):
-            render_step(i)
+        render_steps(0, args.warmup, pipe)
         barrier()
         t0 = time.perf_counter()
-        samples = iters = slots = 0
-        for i in range(args.steps):
-            s, it, sl = render_step(args.warmup + i)
-            samples += s
-            iters += it
-            slots += sl
+        samples, iters, slots = render_steps(args.warmup, args.steps, pipe)
         barrier()
         elapsed = time.perf_counter() - t0
+        if pipe is not None:
+            pipe.shutdown()
 
         # ---- roofline leg: per-launch HIP events around the dominant kernel (k_render_iter), separate pass
         roof = None
@@ -224,6 +250,7 @@ def main():
             "config": {"workload": f"Stonehenge {H}x{W} synthetic, hashgrid L=16 F=2 T=2^19 + ffmlp(64,2)/(64,3), fp16, "
                                    "occupancy-grid ray marching (run_cuda eval path, BASELINE configs[1])",
                        "rays_per_frame": H * W, "bound": sc.bound, "cascade": sc.cascade, "density_scale": sc.density_scale,
+                       "frames_in_flight": args.in_flight,
                        "parallelism": f"camera-sharded x{world}, RCCL all_gather of rendered tiles" if world > 1 else "single GPU"},
             "frames_per_sec": round(frames / elapsed, 3),
             "rays_per_sec": round(frames * H * W / elapsed, 1),

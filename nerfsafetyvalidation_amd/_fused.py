@@ -8,6 +8,7 @@ on the module.  The nn.Linear backbone (nerf/network.py) is zero-padded to the f
     colour: W1 [64,31], W2 [64,64], W3 [3,64]             -> blob [64x32 | 64x64 | 16x64]  (1 hidden matmul)
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -37,10 +38,10 @@ class FusedModel:
         self.cascade, self.grid_size = net.cascade, net.grid_size
         self._watched = watched
         self._snapshot = _versions(watched)
-        self._ctx = None
-        self._ctx_rays = 0
+        self._ctxs = {}          # one render context per host thread: [handle, capacity] (frames may be in flight on several streams)
+        self._ctx_lock = threading.Lock()
         self._pad = None
-        self.last_stats = None
+        self._tls = threading.local()
 
     # ---- construction from the two backbones ---------------------------------------------------------
     @classmethod
@@ -110,15 +111,25 @@ class FusedModel:
             self._pad = (C.c_float * 4)(float(sig), float(c[0, 0]), float(c[0, 1]), float(c[0, 2]))
         return self._pad
 
+    @property
+    def last_stats(self):
+        """statistics of the calling thread's last render"""
+        return getattr(self._tls, "stats", None)
+
     def _context(self, N):
         lib = _lib.lib()
-        if self._ctx is None or self._ctx_rays < N:
-            if self._ctx is not None:
-                lib.ngp_render_ctx_destroy(self._ctx)
+        key = threading.get_ident()
+        with self._ctx_lock:
+            ent = self._ctxs.get(key)
+        if ent is None or ent[1] < N:
+            if ent is not None:
+                lib.ngp_render_ctx_destroy(ent[0])
             h = C.c_void_p()
             _lib.check(lib.ngp_render_ctx_create(N, C.byref(h)), "render_ctx_create")
-            self._ctx, self._ctx_rays = h, N
-        return self._ctx
+            ent = [h, N]
+            with self._ctx_lock:
+                self._ctxs[key] = ent
+        return ent[0]
 
     def render(self, net_bitfield_owner, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb, want_last=True, want_stats=True,
                frame_width=0):
@@ -145,7 +156,7 @@ class FusedModel:
                    "render_rays")
         sigmas = rgbs = None
         if need_stats:
-            self.last_stats = {"samples_marched": int(stats.samples_marched), "samples_slots": int(stats.samples_slots),
+            self._tls.stats = {"samples_marched": int(stats.samples_marched), "samples_slots": int(stats.samples_slots),
                                "iterations": int(stats.iterations), "rays": int(stats.rays), "launches": int(stats.launches),
                                "replayed": int(stats.replayed)}
         if want_last and stats.iterations > 0:
@@ -173,7 +184,7 @@ class FusedModel:
 
     def __del__(self):
         try:
-            if self._ctx is not None:
-                _lib.lib().ngp_render_ctx_destroy(self._ctx)
+            for ent in self._ctxs.values():
+                _lib.lib().ngp_render_ctx_destroy(ent[0])
         except Exception:
             pass

@@ -13,6 +13,7 @@ What is different underneath:
     the operator-by-operator loop the reference runs.
 """
 import math
+import threading
 
 import numpy as np
 import torch
@@ -20,6 +21,8 @@ import torch.nn as nn
 
 from .. import raymarching
 from .utils import custom_meshgrid
+
+_STATS_TLS = threading.local()   # per-thread `last_render_stats` of every renderer (keyed by id)
 
 
 def sample_pdf(bins, weights, n_samples, det=False):
@@ -82,6 +85,17 @@ class NeRFRenderer(nn.Module):
 
     def color(self, x, d, mask=None, **kwargs):
         raise NotImplementedError()
+
+    # statistics of the last render of the CALLING thread (frames may be rendered from several host threads, pipeline.py)
+    @property
+    def last_render_stats(self):
+        return getattr(_STATS_TLS, "by_model", {}).get(id(self))
+
+    @last_render_stats.setter
+    def last_render_stats(self, value):
+        if not hasattr(_STATS_TLS, "by_model"):
+            _STATS_TLS.by_model = {}
+        _STATS_TLS.by_model[id(self)] = value
 
     def fused_model(self):
         """Networks that ngp_render_rays can evaluate return an `_fused.FusedModel`; others return None."""

@@ -440,3 +440,30 @@ def test_full_size_frame_properties(device):
     missed = want["nears"] >= want["fars"]
     if missed.any():
         assert np.all(img.cpu().numpy()[sel][missed] == 1.0)
+
+
+def test_frame_pipeline_matches_direct_calls(setup, device):
+    """Frames rendered concurrently (two host threads, two streams, one render call each) equal the same calls made one after the
+    other, bit for bit, and every call sees its own statistics."""
+    from nerfsafetyvalidation_amd.pipeline import FramePipeline
+    sc, model, _ = setup
+    views = [3, 50, 97, 140, 199, 12]
+    rays = []
+    for v in views:
+        ro, rd = Hh.pinhole_rays(sc.poses[v], sc.intrinsics, sc.H, sc.W)
+        rays.append((_t(ro, device)[None], _t(rd, device)[None]))
+    direct = []
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        for ro, rd in rays:
+            out = model.render(ro, rd, staged=True, bg_color=1, perturb=False, frame_width=sc.W)
+            direct.append((out["image"].clone(), out["depth"].clone(), dict(model.last_render_stats)))
+        with FramePipeline(model, in_flight=2) as pipe:
+            futures = [pipe.submit(ro, rd, staged=True, bg_color=1, perturb=False, frame_width=sc.W) for ro, rd in rays]
+            results = [f.result() for f in futures]
+    for (img, dep, st), (out, stats, done) in zip(direct, results):
+        torch.cuda.current_stream().wait_event(done)
+        assert out["image"].dtype == img.dtype            # autocast mode of the caller was carried over
+        assert torch.equal(out["image"], img) and torch.equal(out["depth"], dep)
+        for key in ("samples_marched", "samples_slots", "iterations"):
+            assert stats[key] == st[key], key
+    assert len({st["samples_marched"] for _, _, st in direct}) > 1     # the views differ, so mixed-up statistics would show
