@@ -2,9 +2,12 @@
 # Writes everything under gpurun_out/; copy the summaries you want judged into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/kt gpurun_out/pmc? gpurun_out/pmc_summary.json
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 --batched-views 0 --in-flight 1"   # one frame in flight: the conditions of the roofline leg
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- $B > gpurun_out/kt.log 2>&1
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0"
+# the default command (two frames in flight: kernels of the two streams overlap, per-launch durations grow)
+rm -rf gpurun_out/kt2
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt2 -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-steps 0 --batched-views 0 > gpurun_out/kt2.log 2>&1
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --batched-views 0 --in-flight 1"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/pmcA -- $B > gpurun_out/pmcA.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d gpurun_out/pmcB -- $B > gpurun_out/pmcB.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmcC -- $B > gpurun_out/pmcC.log 2>&1
