@@ -67,14 +67,29 @@ def gather_views(local, n_total, group=None):
     return gather_views_start(local, n_total, group).finish()
 
 
-def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None):
+def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None, in_flight=1, device=None):
     """render_view(i) -> dict of tensors for global view i (e.g. {'image': [H*W,3], 'depth': [H*W]}).
-    Each rank renders its contiguous block of views; one all_gather per key returns all views everywhere."""
+    Each rank renders its contiguous block of views; one all_gather per key returns all views everywhere.
+    in_flight > 1 (GPU only, `device` required): that many views of this rank are rendered concurrently, each by its own
+    render_view call on its own host thread and stream (pipeline.FramePipeline); the collectives stay on this thread."""
     if rank is None:
         rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     if world_size is None:
         world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     lo, hi = shard_range(n_views, rank, world_size)
-    outs = [render_view(i) for i in range(lo, hi)]
+    if in_flight > 1 and hi - lo > 1:
+        from .pipeline import FramePipeline
+        with FramePipeline(None, in_flight=in_flight, device=device) as pipe:
+            futures = [pipe.submit_fn(render_view, i) for i in range(lo, hi)]
+            outs = []
+            for f in futures:
+                out, _, done = f.result()
+                cur = torch.cuda.current_stream(pipe.device)
+                cur.wait_event(done)
+                for t in out.values():
+                    t.record_stream(cur)
+                outs.append(out)
+    else:
+        outs = [render_view(i) for i in range(lo, hi)]
     keys = outs[0].keys() if outs else []
     return {k: gather_views(torch.stack([o[k] for o in outs], 0), n_views, group) for k in keys}

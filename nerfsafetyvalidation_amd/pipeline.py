@@ -19,15 +19,17 @@ import torch
 
 
 class FramePipeline:
-    def __init__(self, model, in_flight=2, device=None):
+    def __init__(self, model=None, in_flight=2, device=None):
+        """model: the renderer `submit` calls (may be None when only `submit_fn` is used; then `device` is required)"""
         if in_flight < 1:
             raise ValueError("in_flight must be >= 1")
+        if model is None and device is None:
+            raise ValueError("FramePipeline needs a model or a device")
         self.model = model
-        self.device = device if device is not None else next(model.parameters()).device
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
         self.in_flight = in_flight
         self._pool = ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="ngp-frame")
         self._tls = threading.local()
-        self._autocast = torch.is_autocast_enabled("cuda")
 
     def _stream(self):
         s = getattr(self._tls, "stream", None)
@@ -42,7 +44,7 @@ class FramePipeline:
         with torch.cuda.stream(stream), torch.set_grad_enabled(grad), torch.autocast("cuda", dtype=autocast_dtype or torch.float16,
                                                                                       enabled=autocast_dtype is not None):
             out = fn(*args, **kwargs)
-            stats = self.model.last_render_stats
+            stats = self.model.last_render_stats if self.model is not None else None
             done = torch.cuda.Event()
             done.record(stream)
         return out, stats, done

@@ -467,3 +467,22 @@ def test_frame_pipeline_matches_direct_calls(setup, device):
         for key in ("samples_marched", "samples_slots", "iterations"):
             assert stats[key] == st[key], key
     assert len({st["samples_marched"] for _, _, st in direct}) > 1     # the views differ, so mixed-up statistics would show
+
+
+def test_sharded_sweep_with_frames_in_flight(setup, device):
+    """dist.render_views_sharded (single process: the whole sweep is this rank's block) with two views in flight equals the plain loop."""
+    from nerfsafetyvalidation_amd.dist import render_views_sharded
+    sc, model, _ = setup
+    views = [5, 60, 110, 170]
+
+    def render_view(i):
+        ro, rd = Hh.pinhole_rays(sc.poses[views[i]], sc.intrinsics, sc.H, sc.W)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out = model.render(_t(ro, device)[None], _t(rd, device)[None], staged=True, bg_color=1, perturb=False)
+        return {"image": out["image"][0].float(), "depth": out["depth"][0].float()}
+
+    a = render_views_sharded(render_view, len(views))
+    b = render_views_sharded(render_view, len(views), in_flight=2, device=device)
+    torch.cuda.synchronize()
+    assert a["image"].shape == (len(views), sc.H * sc.W, 3)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])
