@@ -208,7 +208,17 @@ typedef struct ngp_model {
     const uint8_t* density_bitfield; /* [C*H^3/8]                                         */
     uint32_t cascade;             /* C                                                    */
     uint32_t grid_size;           /* H (128)                                              */
+    const void* cell_tables;      /* optional (may be NULL): per-cell corner records of the first cell_levels levels, */
+    uint32_t cell_levels;         /* built by ngp_build_cell_tables; 0, 4, 8, 12 or 16                                */
 } ngp_model;
+
+/* Per-cell corner records: a derived copy of the first n_levels levels of the hash table in which every grid CELL owns the 8
+ * entries its corners map to (32 contiguous bytes), so that the fused kernels read one record per sample and level instead of
+ * gathering 8 entries from up to 4 cache lines.  The values are copies: results do not change.  It trades HBM capacity for
+ * gather work (38 GB for 12 levels of the bound-2 Stonehenge table; the MI355X has 288 GB); rebuild it when the table changes.
+ * ngp_cell_tables_bytes: size of the buffer for n_levels levels (0: not representable). */
+NGP_API size_t ngp_cell_tables_bytes(const ngp_model* model, uint32_t n_levels);
+NGP_API int ngp_build_cell_tables(const ngp_model* model, uint32_t n_levels, void* out, ngp_stream_t stream);
 
 typedef struct ngp_render_stats {
     uint64_t samples_marched;     /* non-padding samples generated (sum over iterations)  */

@@ -8,6 +8,7 @@ on the module.  The nn.Linear backbone (nerf/network.py) is zero-padded to the f
     colour: W1 [64,31], W2 [64,64], W3 [3,64]             -> blob [64x32 | 64x64 | 16x64]  (1 hidden matmul)
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -42,6 +43,11 @@ class FusedModel:
         self._ctx_lock = threading.Lock()
         self._pad = None
         self._tls = threading.local()
+        # per-cell corner records (ngp_build_cell_tables): built on first use within this budget (GB); 0 disables them
+        self.cell_table_gb = float(os.environ.get("NGP_CELL_TABLE_GB", getattr(net, "fused_cell_table_gb", 48)))
+        self._cells = None
+        self._cell_levels = 0
+        self._cells_ready = False
 
     # ---- construction from the two backbones ---------------------------------------------------------
     @classmethod
@@ -88,11 +94,35 @@ class FusedModel:
         m.bound, m.density_scale = self.bound, self.density_scale
         m.density_bitfield = _lib.ptr(bitfield) if bitfield is not None else None
         m.cascade, m.grid_size = self.cascade, self.grid_size
+        m.cell_tables = _lib.ptr(self._cells) if self._cells is not None else None
+        m.cell_levels = self._cell_levels
         return m
+
+    def _ensure_cells(self):
+        """Expand the first twelve levels when the budget and a third of the free device memory allow."""
+        if self._cells_ready:
+            return
+        with self._ctx_lock:
+            if self._cells_ready:
+                return
+            lib = _lib.lib()
+            m = self._struct(None)
+            free, _ = torch.cuda.mem_get_info(self.device)
+            budget = min(self.cell_table_gb * (1 << 30), free / 3)
+            for n in (12,):          # (the kernels are specialised for exactly twelve expanded levels)
+                nbytes = lib.ngp_cell_tables_bytes(C.byref(m), n)
+                if 0 < nbytes <= budget:
+                    cells = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                    _lib.check(lib.ngp_build_cell_tables(C.byref(m), n, _lib.ptr(cells), _lib.stream()), "build_cell_tables")
+                    torch.cuda.current_stream(self.device).synchronize()   # other streams may render with it next
+                    self._cells, self._cell_levels = cells, n
+                    break
+            self._cells_ready = True
 
     def network_forward(self, xyzs, dirs):
         """fused NeRFNetwork.forward: xyzs, dirs [M,3] f32 -> sigma [M] f32 (unscaled), rgb [M,3] f32 (fp16-rounded)"""
         xyzs, dirs = xyzs.float().contiguous(), dirs.float().contiguous()
+        self._ensure_cells()
         M = xyzs.shape[0]
         sigmas = torch.empty(M, dtype=torch.float32, device=xyzs.device)
         rgbs = torch.empty(M, 3, dtype=torch.float32, device=xyzs.device)
@@ -136,6 +166,7 @@ class FusedModel:
         """eval-mode body of run_cuda -> weights_sum [N], depth [N], image [N,3], last sigmas, last rgbs.
         frame_width: the rays are the pixels of row-major frames this wide (scheduling hint, results do not depend on it)"""
         bitfield = net_bitfield_owner.density_bitfield
+        self._ensure_cells()
         N = rays_o.shape[0]
         dev = rays_o.device
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
@@ -168,6 +199,7 @@ class FusedModel:
     def render_uniform(self, rays_o, rays_d, nears, fars, num_steps, dump_begin):
         """NeRFRenderer.run without upsampling for ALL rays in one launch -> weights_sum, depth, image (no background), aggregated
         density [N] and the per-sample sigmas [(N-dump_begin)*T, 1] / rgbs [N-dump_begin, T, 3] of the rays >= dump_begin"""
+        self._ensure_cells()
         N, T, dev = rays_o.shape[0], int(num_steps), rays_o.device
         lin = torch.linspace(0.0, 1.0, T, device=dev)
         out = [torch.empty(N, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),

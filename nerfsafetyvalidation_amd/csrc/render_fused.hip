@@ -90,6 +90,7 @@ struct LevelTab {
     uint32_t a1[16], a2[16];   // per-dimension multipliers: the hash primes for hashed levels, the dense strides otherwise
     uint32_t mask[16];         // index reduction as an AND: size-1 (power-of-two size), ~0 (dense: already < size)
     uint32_t flags[16];        // bit0 hashed, bit1 needs a generic modulo (only in the GENERIC kernel variants)
+    uint32_t cell_off[16], cell_res[16];   // per-cell corner records (NetArgs::cells): first record and cells per axis
 };
 
 struct NetArgs {
@@ -98,6 +99,11 @@ struct NetArgs {
     uint32_t sig_mm, col_mm;   // hidden->hidden matmuls
     float bound, inv_two_bound, density_scale;
     int align_corners;
+    // per-cell corner records of the first 4 * cell_steps levels (ngp_build_cell_tables), or null: record (level, cx, cy, cz) =
+    // the 8 table entries the cell's corners map to, 32 contiguous bytes instead of 8 gathers from up to 4 cache lines
+    const uint4* cells;
+    uint32_t cell_steps;
+    uint32_t cell_off[16];     // first record of a level
 };
 
 __host__ __device__ inline uint32_t sig_halfs(uint32_t mm) { return 2048 + mm * 4096 + 1024; }
@@ -221,7 +227,7 @@ __device__ __forceinline__ float fma_mix_hi(float w, uint32_t packed, float acc)
 }
 
 // density half: hash-grid encode + sigma net.  Returns sigma (meaningful in q == 0) and the sigma-net outputs 4q..4q+3 as fp16.
-template <bool GENERIC>
+template <int MODE>
 __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
                                             float& sigma, _Float16 (&s16)[4]) {
     const uint32_t q = lane >> 4;
@@ -251,6 +257,15 @@ __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* W
             g[d] = (uint32_t)fl_;
             fr[i][d] = p[d] - (float)g[d];
         }
+        if (MODE == 2 && i < 3) {   // levels 0..11 from the per-cell records (compile-time: no second code path in the other kernels)
+            const uint32_t S = lt.cell_res[level];
+            const uint32_t ci = lt.cell_off[level] + g[0] + S * (g[1] + S * g[2]);
+            const uint4* rec = na.cells + (size_t)ci * 2;
+            const uint4 lo = rec[0], hi = rec[1];
+            raw[i][0] = lo.x; raw[i][1] = lo.y; raw[i][2] = lo.z; raw[i][3] = lo.w;
+            raw[i][4] = hi.x; raw[i][5] = hi.y; raw[i][6] = hi.z; raw[i][7] = hi.w;
+            continue;
+        }
         const uint32_t* tab = na.table + lt.offset[level];
         const uint32_t t1[2] = {g[1] * a1, g[1] * a1 + a1};
         const uint32_t t2[2] = {g[2] * a2, g[2] * a2 + a2};
@@ -259,7 +274,7 @@ __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* W
             const uint32_t px = g[0] + (idx & 1), ty = t1[(idx >> 1) & 1], tz = t2[(idx >> 2) & 1];
             uint32_t e = hashed ? (px ^ ty ^ tz) : (px + ty + tz);
             e &= mask;
-            if (GENERIC) {
+            if (MODE == 1) {
                 if (fl & 2u) e %= lt.size[level];
             }
             raw[i][idx] = tab[e];
@@ -322,11 +337,11 @@ __device__ __forceinline__ void net_color(const NetArgs& na, const _Float16* Wld
     cb = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[2])));
 }
 
-template <bool GENERIC>
+template <int MODE>
 __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
                                          float dx, float dy, float dz, float& sigma, float& cr, float& cg, float& cb) {
     _Float16 s16[4];
-    net_density<GENERIC>(na, Wlds, lt, lane, x, y, z, sigma, s16);
+    net_density<MODE>(na, Wlds, lt, lane, x, y, z, sigma, s16);
     net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
 }
 
@@ -347,6 +362,8 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
         lt->a2[l] = lv.hashed[l] ? 805459861u : lv.mul2[l];
         lt->mask[l] = lv.mode[l] == 1 ? (size >> d_dbg_shrink) - 1 : 0xFFFFFFFFu;
         lt->flags[l] = (uint32_t)lv.hashed[l] | (lv.mode[l] == 2 ? 2u : 0u);
+        lt->cell_off[l] = na.cell_off[l];
+        lt->cell_res[l] = lv.resolution[l];
     }
     __syncthreads();
 }
@@ -354,7 +371,7 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
 // ------------------------------------------------------------------------------------------
 // NeRFNetwork.forward on an explicit point list (network_ff.py:51-75)
 // ------------------------------------------------------------------------------------------
-template <bool GENERIC>
+template <int MODE>
 __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels lv, const float* __restrict__ xyzs,
                                                          const float* __restrict__ dirs, uint32_t M, float* __restrict__ sigmas,
                                                          float* __restrict__ rgbs) {
@@ -369,7 +386,7 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
         const uint32_t m = tile * 16 + c;
         const uint32_t mm = m < M ? m : M - 1;
         float sg, r, g, b;
-        net_tile<GENERIC>(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], dirs[(size_t)mm * 3],
+        net_tile<MODE>(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], dirs[(size_t)mm * 3],
                  dirs[(size_t)mm * 3 + 1], dirs[(size_t)mm * 3 + 2], sg, r, g, b);
         if (lane < 16 && m < M) {
             sigmas[m] = sg;
@@ -388,7 +405,7 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
 // weights, depth, colour and weights * sigma.  None of the reference's [N, T, *] intermediates exists in memory; the
 // per-sample sigmas / rgbs it returns for the LAST ray chunk are written only for rays >= dump_begin.
 // ------------------------------------------------------------------------------------------
-template <bool GENERIC>
+template <int MODE>
 __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, const float* __restrict__ nears,
                                                            const float* __restrict__ fars, uint32_t N, uint32_t T,
@@ -421,7 +438,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
             const float z = clampf(oz + dz * zv, aabb_lo, aabb_hi);
             float sigma;
             _Float16 s16[4];
-            net_density<GENERIC>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+            net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
             // ---- lanes 0..15 hold sigma of samples i0..i0+15 (the other quarters compute along with them; only lane < 16 results are used)
             const float z_next = (ii + 1 < T) ? near + span * lin[ii + 1] : 0.0f;
             const float delta = (ii + 1 < T) ? z_next - zv : sample_dist;           // :206-207
@@ -569,7 +586,7 @@ __device__ __forceinline__ void dump_row(const RenderArgs& ra, uint32_t entry, i
 }
 
 // LIN: power-of-two grid with the linear copies of the occupancy bits (Dda::probe_lin); otherwise the Morton-order originals
-template <bool GENERIC, bool LIN>
+template <int MODE, bool LIN>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
@@ -730,7 +747,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                 if (ra.stamps) {   // diagnostics: split the tile into encode+sigma net and colour net, count tile fill
                     const unsigned long long ta = __builtin_amdgcn_s_memtime();
                     _Float16 s16[4];
-                    net_density<GENERIC>(na, Wlds, *lt, lane, x, y, z, sg, s16);
+                    net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sg, s16);
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     const unsigned long long tb = __builtin_amdgcn_s_memtime();
                     net_color(na, Wlds, lane, dx, dy, dz, s16, r, g, b);
@@ -741,7 +758,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     sub_n += 1;
                     sub_f += min(16u, total - tile * 16);
                 } else {
-                    net_tile<GENERIC>(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
+                    net_tile<MODE>(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
                 }
                 if (lane < 16 && valid) {
                     S.sig[slot] = na.density_scale * sg;   // renderer.py:365
@@ -1196,6 +1213,48 @@ static bool g_tile_off = false;         // bit 13 of the debug flags: ignore the
 static uint32_t g_spec_safety_x2 = 0;   // 0: kSpecSafetyX2
 static bool g_sort_off = false;
 
+// per-cell corner records: record r of level l (cells x-fastest, `res` per axis) = the table entries of the cell's 8 corners in
+// the gather's corner order (bit 0 of the corner index = x).  One thread per record.
+__global__ void __launch_bounds__(256) k_build_cells(const uint32_t* __restrict__ table, GridLevels lv, uint32_t level, uint32_t n_cells,
+                                                     uint4* __restrict__ out) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_cells) return;
+    const uint32_t S = lv.resolution[level];
+    const uint32_t cx = r % S, cy = (r / S) % S, cz = r / (S * S);
+    const uint32_t size = lv.offset[level + 1] - lv.offset[level];
+    const bool hashed = lv.hashed[level] != 0;
+    const uint32_t a1 = hashed ? 2654435761u : lv.mul1[level], a2 = hashed ? 805459861u : lv.mul2[level];
+    const uint32_t* tab = table + lv.offset[level];
+    uint32_t v[8];
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const uint32_t px = cx + (idx & 1), ty = (cy + ((idx >> 1) & 1)) * a1, tz = (cz + ((idx >> 2) & 1)) * a2;
+        uint32_t e = hashed ? (px ^ ty ^ tz) : (px + ty + tz);
+        if (lv.mode[level] == 1) e &= size - 1;
+        else if (lv.mode[level] == 2) e %= size;
+        v[idx] = tab[e];
+    }
+    out[(size_t)r * 2] = make_uint4(v[0], v[1], v[2], v[3]);
+    out[(size_t)r * 2 + 1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+
+// records needed for the first n_levels levels (0 when they do not fit 32-bit record indices)
+static uint64_t cell_records(const GridLevels& lv, uint32_t n_levels, uint32_t* off) {
+    uint64_t total = 0;
+    for (uint32_t l = 0; l < n_levels; l++) {
+        if (off) off[l] = (uint32_t)total;
+        const uint64_t S = lv.resolution[l];
+        total += S * S * S;
+    }
+    return total < (1ull << 32) ? total : 0;
+}
+
+static bool needs_generic(const GridLevels& lv) {
+    for (int l = 0; l < 16; l++)
+        if (lv.mode[l] == 2) return true;
+    return false;
+}
+
 static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
     NGP_REQUIRE(m && m->embeddings && m->offsets_host && m->sigma_weights && m->color_weights, "ngp_model: null pointer");
     NGP_REQUIRE(m->L == 16, "fused renderer: the hash grid must have 16 levels with 2 features (got L=%u)", m->L);
@@ -1211,18 +1270,48 @@ static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* pac
     na.inv_two_bound = 1.0f / (2 * m->bound);
     na.density_scale = m->density_scale;
     na.align_corners = m->align_corners;
+    na.cells = nullptr;
+    na.cell_steps = 0;
+    for (int l = 0; l < 16; l++) na.cell_off[l] = 0;
+    if (m->cell_tables && m->cell_levels) {
+        NGP_REQUIRE(m->cell_levels % 4 == 0 && m->cell_levels <= 16, "ngp_model: cell_levels must be 0, 4, 8, 12 or 16 (got %u)", m->cell_levels);
+        NGP_REQUIRE(cell_records(lv, m->cell_levels, na.cell_off) != 0, "ngp_model: the cell tables of %u levels exceed 2^32 records", m->cell_levels);
+        NGP_REQUIRE(((uintptr_t)m->cell_tables & 15) == 0, "ngp_model: cell_tables must be 16-byte aligned");
+        if (m->cell_levels == 12 && !needs_generic(lv)) {   // the kernels are specialised for exactly 12 expanded levels
+            na.cells = reinterpret_cast<const uint4*>(m->cell_tables);
+            na.cell_steps = 3;
+        }
+    }
     return NGP_OK;
-}
-
-static bool needs_generic(const GridLevels& lv) {
-    for (int l = 0; l < 16; l++)
-        if (lv.mode[l] == 2) return true;
-    return false;
 }
 
 static size_t weights_bytes(const NetArgs& na) { return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2; }
 
 extern "C" {
+
+size_t ngp_cell_tables_bytes(const ngp_model* model, uint32_t n_levels) {
+    if (!model || !model->offsets_host || model->L != 16 || n_levels > 16) return 0;
+    GridLevels lv;
+    fill_levels(lv, model->offsets_host, 16, model->S, model->H_base, 3, model->gridtype, model->align_corners != 0);
+    return (size_t)cell_records(lv, n_levels, nullptr) * 32;
+}
+
+int ngp_build_cell_tables(const ngp_model* model, uint32_t n_levels, void* out, ngp_stream_t stream) {
+    NGP_REQUIRE(model && model->embeddings && model->offsets_host && out, "build_cell_tables: null pointer");
+    NGP_REQUIRE(model->L == 16 && n_levels % 4 == 0 && n_levels >= 4 && n_levels <= 16, "build_cell_tables: n_levels must be 4, 8, 12 or 16");
+    NGP_REQUIRE(((uintptr_t)out & 15) == 0, "build_cell_tables: the buffer must be 16-byte aligned");
+    GridLevels lv;
+    fill_levels(lv, model->offsets_host, 16, model->S, model->H_base, 3, model->gridtype, model->align_corners != 0);
+    uint32_t off[16];
+    NGP_REQUIRE(cell_records(lv, n_levels, off) != 0, "build_cell_tables: %u levels exceed 2^32 records", n_levels);
+    for (uint32_t l = 0; l < n_levels; l++) {
+        const uint64_t S = lv.resolution[l];
+        const uint32_t n = (uint32_t)(S * S * S);
+        k_build_cells<<<div_up(n, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const uint32_t*>(model->embeddings), lv, l, n,
+                                                                       reinterpret_cast<uint4*>(out) + (size_t)off[l] * 2);
+    }
+    return check_launch("build_cell_tables");
+}
 
 int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     NGP_REQUIRE(out, "render_ctx_create: null out pointer");
@@ -1368,13 +1457,16 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const bool generic = needs_generic(lv);
+    const bool use_cells = na.cells != nullptr;
     NGP_REQUIRE(lds <= 160 * 1024, "render_rays: LDS budget exceeded (%zu bytes)", lds);
 
     uint32_t ub = N;          // host-side upper bound of n_alive
@@ -1393,10 +1485,12 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.heads = ctx->heads + cur;
         {
             ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
-            if (generic && lin) k_render_iter<true, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else if (generic) k_render_iter<true, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else if (lin) k_render_iter<false, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else k_render_iter<false, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            if (generic && lin) k_render_iter<1, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else if (generic) k_render_iter<1, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else if (use_cells && lin) k_render_iter<2, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else if (use_cells) k_render_iter<2, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else if (lin) k_render_iter<0, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            else k_render_iter<0, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
@@ -1520,19 +1614,23 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     uint32_t blocks = div_up(N, 4);
     if (blocks > 1024) blocks = 1024;   // 4 workgroups of 4 waves per CU; each wave strides over rays
     ProfScope prof("render_uniform", s, (double)N * T);
     if (needs_generic(lv))
-        k_render_uniform<true><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                        dump_begin, sigmas, rgbs, -model->bound, model->bound);
+        k_render_uniform<1><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                     dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    else if (na.cells)
+        k_render_uniform<2><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                     dump_begin, sigmas, rgbs, -model->bound, model->bound);
     else
-        k_render_uniform<false><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image,
-                                                         aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
+        k_render_uniform<0><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                     dump_begin, sigmas, rgbs, -model->bound, model->bound);
     return check_launch("render_uniform");
 }
 
@@ -1556,16 +1654,18 @@ int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* 
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     const uint32_t n_tiles = div_up(M, 16);
     uint32_t blocks = div_up(n_tiles, 4);
     if (blocks > 1024) blocks = 1024;
     ProfScope prof("network_forward", s, M);
-    if (needs_generic(lv)) k_network_forward<true><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
-    else k_network_forward<false><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    if (needs_generic(lv)) k_network_forward<1><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    else if (na.cells) k_network_forward<2><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    else k_network_forward<0><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
     return check_launch("network_forward");
 }
 

@@ -44,7 +44,7 @@ def test_ctypes_layer_binds_every_symbol():
     assert lib.ngp_version() >= 100
     assert isinstance(lib.ngp_last_error(), bytes)
     assert lib.ngp_march_rays_train_workspace(1000) >= 4000
-    assert ctypes.sizeof(_lib.ModelStruct) == 96 and ctypes.sizeof(_lib.RenderStats) == 40
+    assert ctypes.sizeof(_lib.ModelStruct) == 112 and ctypes.sizeof(_lib.RenderStats) == 40
 
 
 def test_product_never_imports_the_oracle():

@@ -394,6 +394,7 @@ def test_full_size_frame_properties(device):
     ro_t, rd_t = _t(ro, device)[None], _t(rd, device)[None]
 
     def render(flags, o=ro_t, d=rd_t, **kw):
+        nonlocal model
         lib.ngp_debug_disable_march_queue(flags)
         h = torch.zeros(o.shape[1], dtype=torch.int32, device=device)
         lib.ngp_debug_set_sample_hash(h.data_ptr())
@@ -416,6 +417,18 @@ def test_full_size_frame_properties(device):
         assert st_full[key] == st_plain[key], key
     assert st_full["launches"] < st_plain["launches"]
     assert st_full["samples_marched"] > 10_000_000
+    # (a') the per-cell corner records (copies of table entries, one 32-byte record per cell) against plain gathers
+    assert model.fused_model()._cell_levels >= 4
+    model2 = sc.build_model(device)
+    model2.fused_cell_table_gb = 0
+    keep = model
+    model = model2
+    nocell, h_nocell, st_nocell = render(0, frame_width=sc.W)
+    model = keep
+    assert model2.fused_model()._cell_levels == 0
+    for key in ("image", "depth", "sigmas", "rgbs"):
+        assert torch.equal(full[key], nocell[key]), key
+    assert torch.equal(h_full, h_nocell) and st_full["samples_marched"] == st_nocell["samples_marched"]
     # (d)
     again, h_again, st_again = render(0, frame_width=sc.W)
     assert torch.equal(full["image"], again["image"]) and torch.equal(full["depth"], again["depth"]) and torch.equal(h_full, h_again)
