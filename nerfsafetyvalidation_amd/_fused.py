@@ -17,6 +17,9 @@ import torch
 from . import _lib
 
 
+CACHE_LOCK = threading.Lock()   # serialises the (re)building of a network's FusedModel snapshot
+
+
 def _versions(tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors)
 

@@ -69,6 +69,7 @@ class NeRFNetwork(NeRFRenderer):
         from .. import _fused
         if self.bg_radius > 0:
             return None
-        if self._fused_cache is None or not self._fused_cache.valid_for(self):
-            self._fused_cache = _fused.FusedModel.from_ffmlp_network(self)
-        return self._fused_cache
+        with _fused.CACHE_LOCK:      # frames may be rendered from several host threads (pipeline.py): build the snapshot once
+            if self._fused_cache is None or not self._fused_cache.valid_for(self):
+                self._fused_cache = _fused.FusedModel.from_ffmlp_network(self)
+            return self._fused_cache
