@@ -312,6 +312,102 @@ __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* W
     sigma = expf((float)s16[0]);  // trunc_exp forward (activation.py:8-10), meaningful in q == 0
 }
 
+// ---- MODE 2 inside the render loop: the hashed level of a lane (12 + q) is gathered ONE TILE AHEAD --------------------------------
+// With the per-cell records the only loads that still miss far are the 8 gathers of the lane's hashed level.  They are issued for
+// the NEXT tile's sample while this tile's records are in flight and its MLPs run, and consumed a tile later from registers
+// (`pre`).  Order inside a tile: issue this tile's record loads; interpolate the hashed level from `pre` (loaded a tile ago);
+// issue the next tile's hashed gathers into the freed registers; then wait for the records only (vector-memory loads return
+// in order, so the younger gathers stay in flight behind them).
+__device__ __forceinline__ void encoder_unit(const NetArgs& na, float x, float y, float z, float (&u)[3], bool& oob) {
+    u[0] = (x + na.bound) * na.inv_two_bound; u[1] = (y + na.bound) * na.inv_two_bound; u[2] = (z + na.bound) * na.inv_two_bound;
+    oob = (u[0] < 0 || u[0] > 1) || (u[1] < 0 || u[1] > 1) || (u[2] < 0 || u[2] > 1);
+    if (oob) { u[0] = 0.5f; u[1] = 0.5f; u[2] = 0.5f; }
+}
+
+__device__ __forceinline__ void hashed_gather(const NetArgs& na, const LevelTab& lt, uint32_t level, float x, float y, float z, uint32_t (&out)[8]) {
+    float u[3];
+    bool oob;
+    encoder_unit(na, x, y, z, u, oob);
+    const float half_off = na.align_corners ? 0.0f : 0.5f, scale = lt.scale[level];
+    const uint32_t a1 = lt.a1[level], a2 = lt.a2[level], mask = lt.mask[level];
+    const uint32_t g0 = (uint32_t)floorf(fmaf(u[0], scale, half_off)), g1 = (uint32_t)floorf(fmaf(u[1], scale, half_off)),
+                   g2 = (uint32_t)floorf(fmaf(u[2], scale, half_off));
+    const uint32_t* tab = na.table + lt.offset[level];
+    const uint32_t t1[2] = {g1 * a1, g1 * a1 + a1};
+    const uint32_t t2[2] = {g2 * a2, g2 * a2 + a2};
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) out[idx] = tab[((g0 + (idx & 1)) ^ t1[(idx >> 1) & 1] ^ t2[(idx >> 2) & 1]) & mask];
+}
+
+__device__ __forceinline__ void corners_to_feature(const float (&fr)[3], const uint32_t (&raw)[8], bool oob, _Float16& f0, _Float16& f1) {
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const float wx = (idx & 1) ? fr[0] : 1 - fr[0];
+        const float wy = (idx & 2) ? fr[1] : 1 - fr[1];
+        const float wz = (idx & 4) ? fr[2] : 1 - fr[2];
+        const float w = (wx * wy) * wz;
+        a0 = fma_mix_lo(w, raw[idx], a0);
+        a1 = fma_mix_hi(w, raw[idx], a1);
+    }
+    f0 = oob ? (_Float16)0 : (_Float16)a0;
+    f1 = oob ? (_Float16)0 : (_Float16)a1;
+}
+
+// same values and arithmetic as net_density<2>; `pre` holds this tile's hashed-level entries on entry and the next tile's on exit
+__device__ __forceinline__ void net_density_piped(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y,
+                                                  float z, float nx, float ny, float nz, uint32_t (&pre)[8], float& sigma,
+                                                  _Float16 (&s16)[4]) {
+    const uint32_t q = lane >> 4;
+    float u[3];
+    bool oob;
+    encoder_unit(na, x, y, z, u, oob);
+    const float half_off = na.align_corners ? 0.0f : 0.5f;
+    uint4 rec[3][2];
+    float fr[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t level = q + 4 * i;
+        const float scale = lt.scale[level];
+        uint32_t g[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float p = fmaf(u[d], scale, half_off);
+            g[d] = (uint32_t)floorf(p);
+            fr[i][d] = p - (float)g[d];
+        }
+        if (i < 3) {
+            const uint32_t S = lt.cell_res[level];
+            const uint4* r = na.cells + (size_t)(lt.cell_off[level] + g[0] + S * (g[1] + S * g[2])) * 2;
+            rec[i][0] = r[0];
+            rec[i][1] = r[1];
+        }
+    }
+    half8 feat;
+    {
+        _Float16 f0, f1;
+        corners_to_feature(fr[3], pre, oob, f0, f1);
+        feat[6] = f0; feat[7] = f1;
+    }
+    // (unconditional: a branch here makes the compiler wait for ALL outstanding loads at the join; the last tile re-gathers its own entries)
+    hashed_gather(na, lt, q + 12, nx, ny, nz, pre);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const uint32_t raw[8] = {rec[i][0].x, rec[i][0].y, rec[i][0].z, rec[i][0].w, rec[i][1].x, rec[i][1].y, rec[i][1].z, rec[i][1].w};
+        _Float16 f0, f1;
+        corners_to_feature(fr[i], raw, oob, f0, f1);
+        feat[2 * i] = f0; feat[2 * i + 1] = f1;
+    }
+    const half8* Ws = reinterpret_cast<const half8*>(Wlds);
+    half8 h[2];
+    mlp_in(Ws, lane, feat, h);
+    for (uint32_t k = 0; k < na.sig_mm; k++) mlp_hidden(Ws + 256 + k * 512, lane, h);
+    const f32x4 so = mlp_out(Ws + 256 + na.sig_mm * 512, lane, h);
+#pragma unroll
+    for (int r = 0; r < 4; r++) s16[r] = (_Float16)so[r];
+    sigma = expf((float)s16[0]);
+}
+
 // colour half: SH degree 4 + geo_feat -> colour net -> fp16 sigmoid (results in q == 0)
 __device__ __forceinline__ void net_color(const NetArgs& na, const _Float16* Wlds, uint32_t lane, float dx, float dy, float dz,
                                           const _Float16 (&s16)[4], float& cr, float& cg, float& cb) {
@@ -732,6 +828,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             wave_samples += total;
             const uint32_t n_tiles = (total + 15) / 16;
             unsigned long long sub_a = 0, sub_b = 0, sub_n = 0, sub_f = 0;   // diagnostics only
+            uint32_t pre[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // MODE 2: the lane's hashed-level entries, gathered a tile ahead
             for (uint32_t tile = 0; tile < n_tiles; tile++) {
                 const uint32_t j = tile * 16 + c;
                 const bool valid = j < total;
@@ -757,6 +854,19 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     sub_b += tc - tb;
                     sub_n += 1;
                     sub_f += min(16u, total - tile * 16);
+                } else if (MODE == 2) {
+                    // the hashed level is gathered one tile ahead (net_density_piped): position of the next tile's sample of this lane
+                    const uint32_t jn = (tile + 1) * 16 + c;
+                    const uint32_t en = S.list[jn < total ? jn : total - 1];      // (past the last tile: a valid entry, loaded for nothing)
+                    const uint32_t rn = en >> 3;
+                    const float tn = S.t[rn * kCh + (en & 7)];
+                    const float nx = clampf(fmaf(tn, S.od[rn][3], S.od[rn][0]), -na.bound, na.bound);
+                    const float ny = clampf(fmaf(tn, S.od[rn][4], S.od[rn][1]), -na.bound, na.bound);
+                    const float nz = clampf(fmaf(tn, S.od[rn][5], S.od[rn][2]), -na.bound, na.bound);
+                    if (tile == 0) hashed_gather(na, *lt, (lane >> 4) + 12, x, y, z, pre);
+                    _Float16 s16[4];
+                    net_density_piped(na, Wlds, *lt, lane, x, y, z, nx, ny, nz, pre, sg, s16);
+                    net_color(na, Wlds, lane, dx, dy, dz, s16, r, g, b);
                 } else {
                     net_tile<MODE>(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
                 }
