@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the flow)")
-    p.add_argument("--in-flight", type=int, default=2, help="frames rendered concurrently per GPU, each by its own render call on its own stream "
+    p.add_argument("--in-flight", type=int, default=3, help="frames rendered concurrently per GPU, each by its own render call on its own stream "
                                                            "(nerfsafetyvalidation_amd.pipeline.FramePipeline); 1 = strictly one after the other")
     p.add_argument("--batched-views", type=int, default=4, help="extra, untimed leg: cameras per render call (0 = skip); reported under 'batched'")
     p.add_argument("--no-last", action="store_true", help="do not materialise the last iteration's sigmas/rgbs tensors")
@@ -185,7 +185,7 @@ def main():
                         "achieved_bytes_per_launch": round(algo_bytes / n_launch.value), "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
                         "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
                         "measured_with": "one frame in flight (separate single-stream pass; rocprofv3 twin: `bench.py --in-flight 1`, "
-                                         "profiles/r01_bench_kernel_stats_v8.csv).  With two frames in flight the two streams' launches overlap "
+                                         "profiles/r01_bench_kernel_stats_v8.csv).  With several frames in flight the streams' launches overlap "
                                          "and their durations are not additive",
                         "algorithmic_bytes_per_sample": TABLE_BYTES_PER_SAMPLE, "algorithmic_bytes_per_ray_iteration": RAY_BYTES_PER_RAY_ITER}
 

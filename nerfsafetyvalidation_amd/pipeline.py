@@ -4,7 +4,7 @@ One 800x800 frame is ~15 dependent launches whose tails leave the GPU partly idl
 the next launch cannot start: it needs the compacted list of survivors).  Frames are independent, so a second frame rendered on
 another HIP stream fills those tails: the hardware starts its workgroups as the first frame's finish.  Every frame is still
 rendered by its own `model.render(...)` call -- same arguments, same results as calling it directly; this class only supplies the
-host threads and streams (measured on MI355X: 181 -> 224 frames/s with two frames in flight, 232 with three).
+host threads and streams (measured on MI355X: 195 -> 242 frames/s with two frames in flight, 260 with three).
 
     pipe = FramePipeline(model, in_flight=2)
     futures = [pipe.submit(rays_o, rays_d, staged=True, bg_color=1, perturb=False) for rays_o, rays_d in frames]
