@@ -12,10 +12,10 @@ poses = torch.from_numpy(sc.poses).to(dev)
 buf = torch.zeros(16, dtype=torch.int64, device=dev)
 with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
     for v in (0, 1):
-        r = get_rays(poses[v:v+1], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False)
+        r = get_rays(poses[v:v+1], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False, frame_width=800)
     lib.ngp_debug_set_stamps(buf.data_ptr())
     for v in (2, 3, 4):
-        r = get_rays(poses[v:v+1], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False)
+        r = get_rays(poses[v:v+1], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False, frame_width=800)
     torch.cuda.synchronize(); lib.ngp_debug_set_stamps(None)
 b = buf.cpu().tolist(); tot = sum(b[:4])
 for n, v in zip(['march', 'encode+mlp tiles', 'composite', 'compaction+barrier'], b[:4]): print(f'{n:22s} {v:16d} {100*v/tot:6.2f} %')
@@ -26,7 +26,7 @@ ms, n, u = C.c_double(), C.c_uint64(), C.c_double()
 lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
 with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
     t0 = __import__('time').perf_counter()
-    r = get_rays(poses[5:6], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False)
+    r = get_rays(poses[5:6], sc.intrinsics, 800, 800); model.render(r['rays_o'], r['rays_d'], bg_color=1, perturb=False, frame_width=800)
     torch.cuda.synchronize()
 lib.ngp_prof_enable(0)
 _lib.check(lib.ngp_prof_read(b"k_render_iter", C.byref(ms), C.byref(n), C.byref(u)))
