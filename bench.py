@@ -185,7 +185,7 @@ def main():
                         "achieved_bytes_per_launch": round(algo_bytes / n_launch.value), "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
                         "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
                         "measured_with": "one frame in flight (separate single-stream pass; rocprofv3 twin: `bench.py --in-flight 1`, "
-                                         "profiles/r01_bench_kernel_stats_v8.csv).  With several frames in flight the streams' launches overlap "
+                                         "profiles/r01_bench_kernel_stats_v9.csv).  With several frames in flight the streams' launches overlap "
                                          "and their durations are not additive",
                         "algorithmic_bytes_per_sample": TABLE_BYTES_PER_SAMPLE, "algorithmic_bytes_per_ray_iteration": RAY_BYTES_PER_RAY_ITER}
 
