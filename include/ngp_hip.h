@@ -209,7 +209,7 @@ typedef struct ngp_model {
     uint32_t cascade;             /* C                                                    */
     uint32_t grid_size;           /* H (128)                                              */
     const void* cell_tables;      /* optional (may be NULL): per-cell corner records of the first cell_levels levels, */
-    uint32_t cell_levels;         /* built by ngp_build_cell_tables; 0, 4, 8, 12 or 16                                */
+    uint32_t cell_levels;         /* built by ngp_build_cell_tables; the fused kernels use the records when this is 12 */
 } ngp_model;
 
 /* Per-cell corner records: a derived copy of the first n_levels levels of the hash table in which every grid CELL owns the 8
