@@ -254,6 +254,8 @@ def main():
                                    "occupancy-grid ray marching (run_cuda eval path, BASELINE configs[1])",
                        "rays_per_frame": H * W, "bound": sc.bound, "cascade": sc.cascade, "density_scale": sc.density_scale,
                        "frames_in_flight": args.in_flight,
+                       "frames_in_flight_note": "every frame is rendered by its own NeRFRenderer.render call (800x800 rays); up to this many calls "
+                                                "run concurrently on separate host threads / HIP streams (pipeline.FramePipeline)",
                        "parallelism": f"camera-sharded x{world}, RCCL all_gather of rendered tiles" if world > 1 else "single GPU"},
             "frames_per_sec": round(frames / elapsed, 3),
             "rays_per_sec": round(frames * H * W / elapsed, 1),
