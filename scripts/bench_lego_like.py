@@ -29,6 +29,16 @@ for bound, radius in ((1, 3.2), (2, 1.5)):
             st = model.last_render_stats
             samples += st["samples_marched"]; rollbacks += st["replayed"]; launches += st["launches"]; iters += st["iterations"]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        # the same frames, three in flight (pipeline.FramePipeline)
+        from nerfsafetyvalidation_amd.pipeline import FramePipeline
+        def frame_stats(v):
+            frame(v)
+            return model.last_render_stats["samples_marched"]
+        with FramePipeline(model, in_flight=3) as pipe:
+            [f.result() for f in [pipe.submit_fn(frame_stats, v) for v in range(3)]]
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            s3 = sum(f.result()[0] for f in [pipe.submit_fn(frame_stats, v * 7 % 200) for v in range(3, 3 + n)])
+            torch.cuda.synchronize(); dt3 = time.perf_counter() - t1
     print(json.dumps({"bound": bound, "camera_radius": radius, "frame": f"{H}x{W}", "ms_per_frame": round(dt / n * 1e3, 3),
                       "samples_per_s": round(samples / dt), "samples_per_frame": round(samples / n), "launches_per_frame": round(launches / n, 1), "reference_iterations_per_frame": round(iters / n, 1),
-                      "rollbacks_per_frame": round(rollbacks / n, 2)}))
+                      "rollbacks_per_frame": round(rollbacks / n, 2), "three_in_flight": {"ms_per_frame": round(dt3 / n * 1e3, 3), "samples_per_s": round(s3 / dt3)}}))
