@@ -53,6 +53,14 @@ struct GridLevels {
 void fill_levels(GridLevels& lv, const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t D, uint32_t gridtype,
                  bool align_corners);
 
+// derived copies of the occupancy bits (defined in render_fused.hip, shared with march_rays_train): x-fastest re-layout and its
+// 1:64 reduction (one bit per 4x4x4 block)
+__global__ void k_build_linear(const uint8_t* __restrict__ bitfield, uint32_t cascade, uint32_t logH, uint32_t* __restrict__ lin);
+__global__ void k_build_coarse_linear(const unsigned long long* __restrict__ bitfield64, uint32_t cascade, uint32_t logH,
+                                      unsigned long long* __restrict__ coarse);
+constexpr size_t kTrainLinBytes = 1u << 20;      // march_rays_train keeps them in its workspace when C * H^3 / 8 fits this
+constexpr size_t kTrainCoarseBytes = 8192;
+
 // ---- device helpers ---------------------------------------------------------------
 // fp16(w * g) with the reference's two roundings (fp32 product, then fp16; c10::Half arithmetic,
 // gridencoder.cu:169-172).  The empty asm keeps hipcc from folding the multiply and the conversion

@@ -98,18 +98,33 @@ __global__ void __launch_bounds__(kBlock) k_packbits(const float* __restrict__ g
 
 // ------------------------------------------------------------------ march_rays_train :313-484
 // Phase A: count occupied steps per ray (the reference's first pass) + per-block sums.
+// LIN: power-of-two grid with the derived copies of the occupancy bits in the workspace (x-fastest layout read through
+// Dda::probe_lin, its 4x4x4-block reduction staged in LDS): the same probes and the same t, cheaper (see ngp_common.hpp)
+struct TrainLin {
+    const uint32_t* lin;
+    const uint32_t* coarse;
+    uint32_t coarse_words, logH;
+};
+
+template <bool LIN>
 __global__ void __launch_bounds__(kBlock) k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                               const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                               uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                               const float* __restrict__ nears, const float* __restrict__ fars,
                                                               uint32_t perturb, Pcg32 rng, uint32_t* __restrict__ counts,
-                                                              uint32_t* __restrict__ block_sums) {
+                                                              uint32_t* __restrict__ block_sums, TrainLin tl) {
     __shared__ uint32_t wave_sums[kBlock / 64];
+    __shared__ uint32_t coarse_lds[LIN ? kTrainCoarseBytes / 4 : 1];
+    if (LIN) {
+        for (uint32_t i = threadIdx.x; i < tl.coarse_words; i += kBlock) coarse_lds[i] = tl.coarse[i];
+        __syncthreads();
+    }
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     uint32_t num_steps = 0;
     if (n < N) {
         Dda s;
         s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
+        if (LIN) s.init_lin(tl.lin, tl.logH, true);
         const float far = fars[n];
         float t = nears[n];
         if (perturb) {
@@ -118,7 +133,7 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(const float* __res
         }
         float x, y, z, dt;
         while (t < far && num_steps < max_steps) {
-            if (s.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
+            if (LIN ? s.probe_lin(t, x, y, z, dt, coarse_lds) : s.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
         }
         counts[n] = num_steps;
     }
@@ -173,6 +188,7 @@ __global__ void __launch_bounds__(1024) k_march_train_scan(uint32_t* __restrict_
 }
 
 // Phase C: block-local exclusive scan of counts + block offset -> slot; second DDA pass writes.
+template <bool LIN>
 __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                               const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                               uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
@@ -180,8 +196,11 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __res
                                                               uint32_t perturb, Pcg32 rng, const uint32_t* __restrict__ counts,
                                                               const uint32_t* __restrict__ block_offsets, const uint32_t* __restrict__ base,
                                                               float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
-                                                              int32_t* __restrict__ rays) {
+                                                              int32_t* __restrict__ rays, TrainLin tl) {
     __shared__ uint32_t wave_tot[kBlock / 64];
+    __shared__ uint32_t coarse_lds[LIN ? kTrainCoarseBytes / 4 : 1];
+    if (LIN)
+        for (uint32_t i = threadIdx.x; i < tl.coarse_words; i += kBlock) coarse_lds[i] = tl.coarse[i];
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t num_steps = n < N ? counts[n] : 0;
@@ -208,6 +227,7 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __res
 
     Dda s;
     s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
+    if (LIN) s.init_lin(tl.lin, tl.logH, true);
     const float far = fars[n];
     float t = nears[n];
     if (perturb) {
@@ -220,7 +240,7 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __res
     uint32_t step = 0;
     float last_t = t, x, y, z, dt;
     while (t < far && step < num_steps) {
-        if (s.probe(t, x, y, z, dt)) {
+        if (LIN ? s.probe_lin(t, x, y, z, dt, coarse_lds) : s.probe(t, x, y, z, dt)) {
             pxyz[0] = x; pxyz[1] = y; pxyz[2] = z;
             pdir[0] = s.dx; pdir[1] = s.dy; pdir[2] = s.dz;
             t += dt;
@@ -503,10 +523,12 @@ int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
     return check_launch("packbits");
 }
 
-size_t ngp_march_rays_train_workspace(uint32_t N) {
+static size_t train_counts_bytes(uint32_t N) {
     const size_t nblocks = div_up(N ? N : 1, kBlock);
-    return (size_t)(N + nblocks + 4) * sizeof(uint32_t);
+    return (((size_t)(N + nblocks + 4) * sizeof(uint32_t)) + 15) & ~(size_t)15;
 }
+
+size_t ngp_march_rays_train_workspace(uint32_t N) { return train_counts_bytes(N) + kTrainLinBytes + kTrainCoarseBytes; }
 
 int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
                          uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
@@ -527,11 +549,36 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
     Pcg32 rng;
     rng.seed(42u);  // raymarching.cu:489 hard-coded seed
     ProfScope prof("march_rays_train", s, N);
-    k_march_train_count<<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb, rng,
-                                                   counts, block_sums);
+    // power-of-two grid whose bits fit the workspace: derived copies of the occupancy bits (a few microseconds) and the cheaper probes
+    const size_t cells = (size_t)C * H * H * H;
+    uint32_t logH = 0;
+    while ((1u << logH) < H) logH++;
+    TrainLin tl = {};
+    const bool lin = (1u << logH) == H && H >= 8 && cells % 4096 == 0 && cells / 8 <= kTrainLinBytes && cells / 64 / 8 <= kTrainCoarseBytes &&
+                     ((uintptr_t)grid & 7) == 0 && N >= 1024;
+    if (lin) {
+        char* extra = (char*)workspace + train_counts_bytes(N);
+        uint32_t* lin_bits = (uint32_t*)extra;
+        unsigned long long* coarse = (unsigned long long*)(extra + kTrainLinBytes);
+        k_build_linear<<<div_up((uint32_t)(cells / 32), 256), 256, 0, s>>>(grid, C, logH, lin_bits);
+        k_build_coarse_linear<<<div_up((uint32_t)(cells / 64), 256), 256, 0, s>>>((const unsigned long long*)grid, C, logH, coarse);
+        tl.lin = lin_bits;
+        tl.coarse = (const uint32_t*)coarse;
+        tl.coarse_words = (uint32_t)(cells / 64 / 32);
+        tl.logH = logH;
+        k_march_train_count<true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb, rng,
+                                                             counts, block_sums, tl);
+    } else {
+        k_march_train_count<false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb, rng,
+                                                              counts, block_sums, tl);
+    }
     k_march_train_scan<<<1, 1024, 0, s>>>(block_sums, nblocks, N, counter, base);
-    k_march_train_write<<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
-                                                   counts, block_sums, base, xyzs, dirs, deltas, rays);
+    if (lin)
+        k_march_train_write<true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
+                                                             counts, block_sums, base, xyzs, dirs, deltas, rays, tl);
+    else
+        k_march_train_write<false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
+                                                              counts, block_sums, base, xyzs, dirs, deltas, rays, tl);
     return check_launch("march_rays_train");
 }
 
