@@ -997,10 +997,10 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
                                                          const uint32_t* __restrict__ chunk_count, int32_t* __restrict__ alive_out, uint32_t N,
                                                          uint32_t max_steps, const unsigned long long* __restrict__ stat_shards,
                                                          QueueHeads* __restrict__ nxt_heads, unsigned long long* __restrict__ host_slot, uint32_t seq,
-                                                         uint32_t* __restrict__ death_shards, uint32_t spec_allowed, const int32_t* __restrict__ alive_in,
+                                                         const uint32_t* __restrict__ death_shards, uint32_t spec_allowed, const int32_t* __restrict__ alive_in,
                                                          const float4* __restrict__ backup, float* __restrict__ rays_t, float* __restrict__ weights_sum,
                                                          float* __restrict__ depth, float* __restrict__ image, uint32_t* __restrict__ sample_hash,
-                                                         unsigned long long* stat_shards_rw) {
+                                                         unsigned long long* stat_shards_rw, uint32_t* __restrict__ death_next) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
     const Ctl c = *cur;
@@ -1063,7 +1063,8 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
             n.rollbacks = c.rollbacks + 1;
             n.backoff = 2;                                        // the next two iterations run one per launch
-            for (int i = 0; i < kDeathShards * (int)kSpecK; i++) death_shards[i] = 0;
+            // (this launch's death counts are NOT cleared here: the other blocks of this kernel are still reading them for their
+            //  verdict.  Launches alternate between two buffers; a buffer is cleared right before a multi-iteration launch uses it.)
             for (int i = 0; i < kStatShards; i++) stat_shards_rw[i] = 0ull;   // the discarded launch's sample counts
             *nxt = n;
             for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
@@ -1140,7 +1141,6 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             n.iters = c.iters + it;
             n.samples_slots = slots;
             n.step = c.step + it * q;
-            for (int i = 0; i < kDeathShards * (int)kSpecK; i++) death_shards[i] = 0;
         }
         uint32_t ns = n.n_alive ? N / n.n_alive : 8;
         n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
@@ -1169,6 +1169,8 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             K = K < room ? K : room;
             if (K >= 2) { n.spec = q; n.n_step = K * q; }
         }
+        if (n.spec)   // the next launch counts deaths per iteration: its buffer (not the one this kernel's blocks are reading) starts at zero
+            for (int i = 0; i < kDeathShards * (int)kSpecK; i++) death_next[i] = 0;
         *nxt = n;
         for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
         publish_status(host_slot, n, seq);
@@ -1183,7 +1185,7 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
                                                       uint32_t tile_w) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n < (uint32_t)kStatShards) stat_shards[n] = 0ull;
-    if (n < (uint32_t)kDeathShards * kSpecK) death_shards[n] = 0;
+    if (n < 2u * (uint32_t)kDeathShards * kSpecK) death_shards[n] = 0;   // both buffers (launches alternate between them)
     if (n < 16) heads[n >> 3].head[n & 7][0] = 0;
     if (n < N) {
         if (sample_hash) sample_hash[n] = 2166136261u;
@@ -1438,7 +1440,7 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->coarse, kCoarseMaxBytes) == hipSuccess;
     ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
     ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
-    ok &= hipMalloc(&c->death_shards, (size_t)kDeathShards * kSpecK * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&c->death_shards, 2 * (size_t)kDeathShards * kSpecK * sizeof(uint32_t)) == hipSuccess;   // two buffers, by launch parity
     ok &= hipMalloc(&c->backup, (size_t)max_rays * 2 * sizeof(float4)) == hipSuccess;
     ok &= hipMalloc(&c->heads, 2 * sizeof(QueueHeads)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
@@ -1513,7 +1515,6 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     ra.last_sigmas = last_sigmas; ra.last_rgbs = last_rgbs;
     if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
     ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count; ra.stat_shards = ctx->stat_shards;
-    ra.death_shards = ctx->death_shards;
     ra.backup = ctx->backup;
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
@@ -1593,6 +1594,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.alive_in = ctx->alive[cur];
         ra.ctl = ctx->ctl + cur;
         ra.heads = ctx->heads + cur;
+        ra.death_shards = ctx->death_shards + (size_t)cur * kDeathShards * kSpecK;
         {
             ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
             if (generic && lin) k_render_iter<1, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
@@ -1604,9 +1606,10 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
-                                                           ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1, ctx->death_shards,
-                                                           spec_allowed, ctx->alive[cur], ctx->backup, ctx->rays_t, weights_sum, depth, image,
-                                                           g_sample_hash, ctx->stat_shards);
+                                                           ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1,
+                                                           ctx->death_shards + (size_t)cur * kDeathShards * kSpecK, spec_allowed, ctx->alive[cur],
+                                                           ctx->backup, ctx->rays_t, weights_sum, depth, image, g_sample_hash, ctx->stat_shards,
+                                                           ctx->death_shards + (size_t)(cur ^ 1) * kDeathShards * kSpecK);
         launched++;
         launches += 2;
         // consume every status that has already landed; block only when too far ahead

@@ -1,0 +1,41 @@
+"""Two ranks sharing ONE GPU (gloo collectives): the camera-sharded sweep must produce exactly the images a single process
+renders.  Besides the sharding and gather logic this is a contention test: with two processes time-slicing the GPU, workgroups of
+one kernel run far apart in time, which is how a race inside k_render_compact was found (its last workgroup cleared the
+per-iteration death counts other workgroups were still reading for their roll-back verdict)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(ROOT, "scripts", "sweep_200_views.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SWEEP_PER_VIEW="1")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    per_view = [l for l in out.stdout.splitlines() if l.startswith("per-view")][-1]
+    summary = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    return per_view, summary
+
+
+def test_two_ranks_on_one_gpu_render_the_same_images(device):
+    args = ["--views", "12", "--size", "800"]
+    one, s1 = _run([sys.executable, SCRIPT] + args)
+    two, s2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), SCRIPT, "--backend", "gloo"] + args)
+    assert s1["n_gpus"] == 1 and s2["n_gpus"] == 2 and s1["gathered"] == s2["gathered"] == [12, 640000, 3]
+    assert one == two            # per-view sums of the fp16 bit patterns
+    assert s1["checksum"] == s2["checksum"]
