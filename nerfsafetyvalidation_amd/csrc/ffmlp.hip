@@ -605,16 +605,22 @@ __global__ void __launch_bounds__(64) k_ffmlp_bwd_wgrad(const _Float16* __restri
 }
 
 // fixed-order sum of the S partials of every parameter, one rounding to fp16
-__global__ void __launch_bounds__(256) k_ffmlp_bwd_reduce(const float* __restrict__ ws, uint32_t S, uint32_t P,
-                                                          _Float16* __restrict__ grad_weights) {
-    __shared__ float part[4][64];
-    const uint32_t p = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+constexpr int kReduceWaves = 16;
+__global__ void __launch_bounds__(64 * kReduceWaves) k_ffmlp_bwd_reduce(const float* __restrict__ ws, uint32_t S, uint32_t P,
+                                                                        _Float16* __restrict__ grad_weights) {
+    __shared__ float part[kReduceWaves][64];
+    const uint32_t lane = threadIdx.x & 63, p = blockIdx.x * 64 + lane, q = threadIdx.x >> 6;
     float s = 0;
     if (p < P)
-        for (uint32_t k = q; k < S; k += 4) s += ws[(size_t)k * P + p];
-    part[q][threadIdx.x & 63] = s;
+        for (uint32_t k = q; k < S; k += kReduceWaves) s += ws[(size_t)k * P + p];   // wave q: partials q, q + 16, ... in order
+    part[q][lane] = s;
     __syncthreads();
-    if (q == 0 && p < P) grad_weights[p] = (_Float16)(((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
+    if (q == 0 && p < P) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < kReduceWaves; w++) t += part[w][lane];                    // ... then the sixteen sums in order
+        grad_weights[p] = (_Float16)t;
+    }
 }
 
 // fp32 split-K workspace, one per device, grown on demand (the reference's counterpart is the CUTLASS
@@ -737,7 +743,7 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                                                     (const _Float16*)backward_buffer, B, input_dim, hidden_dim, num_layers, chunk, ws, P);
     rc = check_launch("ffmlp_backward (weight gradients)");
     if (rc) return rc;
-    k_ffmlp_bwd_reduce<<<div_up(P, 64), 256, 0, s>>>(ws, S, P, (_Float16*)grad_weights);
+    k_ffmlp_bwd_reduce<<<div_up(P, 64), 64 * kReduceWaves, 0, s>>>(ws, S, P, (_Float16*)grad_weights);
     return check_launch("ffmlp_backward (split-K reduction)");
 }
 
