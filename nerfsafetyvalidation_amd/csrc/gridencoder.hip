@@ -362,7 +362,7 @@ constexpr uint32_t kBinLog = 12, kBinEntries = 1u << kBinLog;    // entries per 
 constexpr uint32_t kBinMax = 128;                                // bins per level (levels of at most 2^19 entries)
 constexpr uint32_t kBinCap = 96;                                 // records per (point block, bin)
 constexpr uint32_t kBinPoints = 1024;                            // points per k_grid_bwd_bin workgroup (one per thread)
-constexpr uint32_t kBinSplit = 8;                                // reducing workgroups per bin
+constexpr uint32_t kBinSplit = 8;                                // reducing workgroups per bin (fewer for small batches)
 // entry -> (bin, slot in the bin).  Hashed levels: bins of 4096 consecutive entries (the hash spreads any batch evenly, and the
 // slice goes back to the table in contiguous atomics).  Dense levels: entries dealt round-robin over 128 bins, so that the
 // spatially clustered updates of a ray bundle still fill the bins evenly (the slice goes back with scattered atomics -- few,
@@ -431,20 +431,21 @@ __global__ void __launch_bounds__(kBinPoints) k_grid_bwd_bin(const _Float16* __r
 
 __global__ void __launch_bounds__(256) k_grid_bwd_bin_reduce(const uint2* __restrict__ records, const uint32_t* __restrict__ counts,
                                                              _Float16* __restrict__ grad_grid, GridLevels lv, BinLevels bl, uint32_t first,
-                                                             uint32_t n_pblocks) {
+                                                             uint32_t n_pblocks, uint32_t n_split) {
     __shared__ float acc[kBinEntries * 2];
     const uint32_t level = bl.level[first + blockIdx.y];
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
     const bool hashed = lv.hashed[level] != 0;
     const uint32_t n_bins = hashed ? (hashmap_size + kBinEntries - 1) >> kBinLog : kBinMax;
-    const uint32_t bin = blockIdx.x / kBinSplit, split = blockIdx.x % kBinSplit;
+    const uint32_t bin = blockIdx.x / n_split, split = blockIdx.x % n_split;
     if (bin >= n_bins) return;
     for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += 256) acc[i] = 0.0f;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // each wave walks its share of the point blocks, four segments in flight; a segment's records are loaded without waiting for
     // its count (slots past the count hold stale bytes and are masked)
-    constexpr uint32_t U = 4, stride = kBinSplit * 4;
+    constexpr uint32_t U = 4;
+    const uint32_t stride = n_split * 4;
     for (uint32_t blk0 = split * 4 + wave; blk0 < n_pblocks; blk0 += stride * U) {
         uint32_t c[U];
         uint2 u0[U];
@@ -633,7 +634,10 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
                 const uint32_t n = n_bin - first < group ? n_bin - first : group;
                 k_grid_bwd_bin<D><<<dim3(n_pb, n), kBinPoints, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype, ac, bl,
                                                                               first, records, counts);
-                k_grid_bwd_bin_reduce<<<dim3(kBinMax * kBinSplit, n), 256, 0, s>>>(records, counts, (_Float16*)grad_emb, lv, bl, first, n_pb);
+                // reducing workgroups per bin: one per ~64 point blocks (each zeroes and flushes a 32 KB slice: not worth it for less)
+                uint32_t n_split = n_pb / 64;
+                n_split = n_split < 1 ? 1 : (n_split > kBinSplit ? kBinSplit : n_split);
+                k_grid_bwd_bin_reduce<<<dim3(kBinMax * n_split, n), 256, 0, s>>>(records, counts, (_Float16*)grad_emb, lv, bl, first, n_pb, n_split);
             }
             for (uint32_t i = 0; i < n_bin; i++) done_mask |= 1u << bl.level[i];
             n_done += n_bin;
