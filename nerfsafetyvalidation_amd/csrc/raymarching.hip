@@ -107,13 +107,15 @@ struct TrainLin {
     uint32_t coarse_words, logH;
 };
 
-template <bool LIN>
+// TRACE (small batches, where a launch is a few dozen waves and the march is a latency chain): the count pass records (t, dt) of
+// every sample it finds, so the write pass replays them instead of marching the ray a second time.
+template <bool LIN, bool TRACE>
 __global__ void __launch_bounds__(kBlock) k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                               const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                               uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                               const float* __restrict__ nears, const float* __restrict__ fars,
                                                               uint32_t perturb, Pcg32 rng, uint32_t* __restrict__ counts,
-                                                              uint32_t* __restrict__ block_sums, TrainLin tl) {
+                                                              uint32_t* __restrict__ block_sums, TrainLin tl, float2* __restrict__ trace) {
     __shared__ uint32_t wave_sums[kBlock / 64];
     __shared__ uint32_t coarse_lds[LIN ? kTrainCoarseBytes / 4 : 1];
     if (LIN) {
@@ -134,7 +136,11 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(const float* __res
         }
         float x, y, z, dt;
         while (t < far && num_steps < max_steps) {
-            if (LIN ? s.probe_lin(t, x, y, z, dt, coarse_lds) : s.probe(t, x, y, z, dt)) { num_steps++; t += dt; }
+            if (LIN ? s.probe_lin(t, x, y, z, dt, coarse_lds) : s.probe(t, x, y, z, dt)) {
+                if (TRACE) trace[(size_t)n * max_steps + num_steps] = make_float2(t, dt);
+                num_steps++;
+                t += dt;
+            }
         }
         counts[n] = num_steps;
     }
@@ -189,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_march_train_scan(uint32_t* __restrict_
 }
 
 // Phase C: block-local exclusive scan of counts + block offset -> slot; second DDA pass writes.
-template <bool LIN>
+template <bool LIN, bool TRACE>
 __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                               const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                               uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
@@ -197,7 +203,7 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __res
                                                               uint32_t perturb, Pcg32 rng, const uint32_t* __restrict__ counts,
                                                               const uint32_t* __restrict__ block_offsets, const uint32_t* __restrict__ base,
                                                               float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
-                                                              int32_t* __restrict__ rays, TrainLin tl) {
+                                                              int32_t* __restrict__ rays, TrainLin tl, const float2* __restrict__ trace) {
     __shared__ uint32_t wave_tot[kBlock / 64];
     __shared__ uint32_t coarse_lds[LIN ? kTrainCoarseBytes / 4 : 1];
     if (LIN)
@@ -245,8 +251,19 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __res
     float bx[12], bd[8];
     uint32_t held = 0;
     const f4u dv0 = {s.dx, s.dy, s.dz, s.dx}, dv1 = {s.dy, s.dz, s.dx, s.dy}, dv2 = {s.dz, s.dx, s.dy, s.dz};
-    while (t < far && step < num_steps) {
-        if (LIN ? s.probe_lin(t, x, y, z, dt, coarse_lds) : s.probe(t, x, y, z, dt)) {
+    while (TRACE ? step < num_steps : (t < far && step < num_steps)) {
+        bool hit;
+        if (TRACE) {   // replay the count pass: the same t, the same position arithmetic as the probe (:369-371)
+            const float2 td = trace[(size_t)n * max_steps + step];
+            t = td.x; dt = td.y;
+            x = clampf(fmaf(t, s.dx, s.ox), -s.bound, s.bound);
+            y = clampf(fmaf(t, s.dy, s.oy), -s.bound, s.bound);
+            z = clampf(fmaf(t, s.dz, s.oz), -s.bound, s.bound);
+            hit = true;
+        } else {
+            hit = LIN ? s.probe_lin(t, x, y, z, dt, coarse_lds) : s.probe(t, x, y, z, dt);
+        }
+        if (hit) {
             t += dt;
             const float d1 = t - last_t;
             last_t = t;
@@ -611,7 +628,12 @@ static size_t train_counts_bytes(uint32_t N) {
     return (((size_t)(N + nblocks + 4) * sizeof(uint32_t)) + 15) & ~(size_t)15;
 }
 
-size_t ngp_march_rays_train_workspace(uint32_t N) { return train_counts_bytes(N) + kTrainLinBytes + kTrainCoarseBytes; }
+constexpr uint32_t kTraceMaxRays = 16384, kTraceMaxSteps = 1024;   // (t, dt) trace of the count pass: 8 bytes per possible sample
+static size_t train_trace_bytes(uint32_t N) { return N <= kTraceMaxRays ? (size_t)N * kTraceMaxSteps * sizeof(float2) : 0; }
+
+size_t ngp_march_rays_train_workspace(uint32_t N) {
+    return train_counts_bytes(N) + kTrainLinBytes + kTrainCoarseBytes + train_trace_bytes(N);
+}
 
 int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
                          uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
@@ -639,6 +661,9 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
     TrainLin tl = {};
     const bool lin = (1u << logH) == H && H >= 8 && cells % 4096 == 0 && cells / 8 <= kTrainLinBytes && cells / 64 / 8 <= kTrainCoarseBytes &&
                      ((uintptr_t)grid & 7) == 0 && N >= 1024;
+    float2* trace = nullptr;
+    if (lin && train_trace_bytes(N) && max_steps <= kTraceMaxSteps)
+        trace = (float2*)((char*)workspace + train_counts_bytes(N) + kTrainLinBytes + kTrainCoarseBytes);
     if (lin) {
         char* extra = (char*)workspace + train_counts_bytes(N);
         uint32_t* lin_bits = (uint32_t*)extra;
@@ -649,19 +674,26 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
         tl.coarse = (const uint32_t*)coarse;
         tl.coarse_words = (uint32_t)(cells / 64 / 32);
         tl.logH = logH;
-        k_march_train_count<true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb, rng,
-                                                             counts, block_sums, tl);
+        if (trace)
+            k_march_train_count<true, true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb,
+                                                                       rng, counts, block_sums, tl, trace);
+        else
+            k_march_train_count<true, false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb,
+                                                                        rng, counts, block_sums, tl, nullptr);
     } else {
-        k_march_train_count<false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb, rng,
-                                                              counts, block_sums, tl);
+        k_march_train_count<false, false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb, rng,
+                                                                     counts, block_sums, tl, nullptr);
     }
     k_march_train_scan<<<1, 1024, 0, s>>>(block_sums, nblocks, N, counter, base);
-    if (lin)
-        k_march_train_write<true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
-                                                             counts, block_sums, base, xyzs, dirs, deltas, rays, tl);
+    if (lin && trace)
+        k_march_train_write<true, true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
+                                                                   counts, block_sums, base, xyzs, dirs, deltas, rays, tl, trace);
+    else if (lin)
+        k_march_train_write<true, false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
+                                                                    counts, block_sums, base, xyzs, dirs, deltas, rays, tl, nullptr);
     else
-        k_march_train_write<false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
-                                                              counts, block_sums, base, xyzs, dirs, deltas, rays, tl);
+        k_march_train_write<false, false><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
+                                                                     counts, block_sums, base, xyzs, dirs, deltas, rays, tl, nullptr);
     return check_launch("march_rays_train");
 }
 
