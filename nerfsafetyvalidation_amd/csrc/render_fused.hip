@@ -333,10 +333,14 @@ __device__ __forceinline__ void hashed_gather(const NetArgs& na, const LevelTab&
     const uint32_t g0 = (uint32_t)floorf(fmaf(u[0], scale, half_off)), g1 = (uint32_t)floorf(fmaf(u[1], scale, half_off)),
                    g2 = (uint32_t)floorf(fmaf(u[2], scale, half_off));
     const uint32_t* tab = na.table + lt.offset[level];
+    const bool hashed = (lt.flags[level] & 1u) != 0;     // (a tiled grid's fine levels are sums wrapped by the mask, not hashes)
     const uint32_t t1[2] = {g1 * a1, g1 * a1 + a1};
     const uint32_t t2[2] = {g2 * a2, g2 * a2 + a2};
 #pragma unroll
-    for (int idx = 0; idx < 8; idx++) out[idx] = tab[((g0 + (idx & 1)) ^ t1[(idx >> 1) & 1] ^ t2[(idx >> 2) & 1]) & mask];
+    for (int idx = 0; idx < 8; idx++) {
+        const uint32_t px = g0 + (idx & 1), ty = t1[(idx >> 1) & 1], tz = t2[(idx >> 2) & 1];
+        out[idx] = tab[(hashed ? (px ^ ty ^ tz) : (px + ty + tz)) & mask];
+    }
 }
 
 __device__ __forceinline__ void corners_to_feature(const float (&fr)[3], const uint32_t (&raw)[8], bool oob, _Float16& f0, _Float16& f1) {
