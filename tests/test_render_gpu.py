@@ -205,6 +205,7 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
     (2, 0.0, True, 2111, 1024),         # jitter: the alive list keeps the reference's order (the jitter is seeded with the list index)
     (1, 1.0 / 256, True, 1000, 512),
     (2, 0.0, False, 4096, 100),         # non-power-of-two step budget
+    (4, 0.0, False, 3000, 1024),        # three cascades; the first twelve levels exceed 2^32 cells: no per-cell records, plain gathers
 ])
 def test_fused_vs_operator_loop_across_configurations(device, bound, dt_gamma, perturb, n_rays, max_steps):
     """The fused renderer against this repo's own operator-by-operator loop (each operator bit-exact with the oracle) on
