@@ -534,3 +534,24 @@ def test_grid_variants_with_and_without_cell_records(device, encoding, align_cor
     assert outs[48][2]["samples_marched"] == outs[0][2]["samples_marched"] > 1000
     d = (outs[0][0] - outs["loop"][0]).abs()
     assert d.max().item() < 6e-3 and d.mean().item() < 3e-4
+
+
+def test_run_path_and_network_forward_with_and_without_cell_records(device):
+    """The `run` path (ngp_render_uniform) and the fused network evaluation (ngp_network_forward) read the first twelve levels from
+    the per-cell records when they exist: same bits as gathering from the table."""
+    sc = _scene(H=32, W=32)
+    ro, rd = Hh.pinhole_rays(sc.poses[77], sc.intrinsics, sc.H, sc.W)
+    xyz, d = _points(sc, 5000, seed=3)
+    outs = []
+    for gb in (48, 0):
+        model = sc.build_model(device, cuda_ray=False)
+        model.fused_cell_table_gb = gb
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            r = model.render(_t(ro, device)[None], _t(rd, device)[None], staged=True, max_ray_batch=4096, bg_color=1, perturb=False,
+                             num_steps=128, upsample_steps=0)
+            sg, rgb = model.fused_model().network_forward(_t(xyz, device), _t(d, device))
+        assert model.fused_model()._cell_levels == (12 if gb else 0)
+        outs.append((r["image"].float().clone(), r["depth"].float().clone(), r["aggregated_density"].float().clone(), sg.clone(), rgb.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][3].abs().max().item() > 0
