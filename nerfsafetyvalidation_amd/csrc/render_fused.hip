@@ -969,7 +969,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         wave_total += wave_samples;
         // padding rows of the reference's [M_padded] tensors (M += 128 - M % 128), written by the last chunk's wave
         if (ra.dump_iter && active) ra.dump_iter[ray] = ctl.iters;
-        if (ra.last_sigmas && !ra.dump_rec && chunk == n_chunks - 1) {
+        if (ra.last_sigmas && !ra.dump_rec && !spec && chunk == n_chunks - 1) {   // (never from a multi-iteration launch: its n_alive * n_step exceeds the tensors)
             for (uint32_t i = lane; i < 128; i += 64) {
                 const size_t row = (size_t)n_alive * n_step + i;
                 ra.last_sigmas[row] = ra.pad_sigma;
@@ -1510,7 +1510,9 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     // scheduling hint (ngp_render_ctx_set_frame_width): whole rows of 4x4-pixel tiles only; not with jitter (seeded with the list index)
     const uint32_t fw = ctx->frame_width;
     const uint32_t tile_w = (perturb == 0 && !g_tile_off && fw >= 4 && fw % 4 == 0 && N % (4 * fw) == 0) ? fw : 0u;
-    k_render_init<<<div_up(N, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
+    // (the grid also has to cover the loop's own counters -- both death-count buffers -- however few rays there are)
+    const uint32_t init_threads = N > 2u * kDeathShards * kSpecK ? N : 2u * kDeathShards * kSpecK;
+    k_render_init<<<div_up(init_threads, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
                                                  g_sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed, tile_w);
 
     RenderArgs ra = {};

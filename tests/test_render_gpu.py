@@ -555,3 +555,21 @@ def test_run_path_and_network_forward_with_and_without_cell_records(device):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert outs[0][3].abs().max().item() > 0
+
+
+def test_batched_cameras_and_partial_frames(setup, device):
+    """rays [B, N, 3] of several cameras in one call are the flattened ray list (renderer.py:263-266): same bits as the [1, B*N, 3] call;
+    a frame-width hint that does not fit the ray count (a subset of a frame) is ignored, not misapplied."""
+    sc, model, _ = setup
+    rays = [Hh.pinhole_rays(sc.poses[v], sc.intrinsics, sc.H, sc.W) for v in (11, 123)]
+    ro = _t(np.stack([r[0] for r in rays]), device)
+    rd = _t(np.stack([r[1] for r in rays]), device)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = model.render(ro, rd, staged=True, bg_color=1, perturb=False, frame_width=sc.W)
+        b = model.render(ro.reshape(1, -1, 3), rd.reshape(1, -1, 3), staged=True, bg_color=1, perturb=False)
+        assert a["image"].shape == (2, sc.H * sc.W, 3) and a["depth"].shape == (2, sc.H * sc.W)
+        assert torch.equal(a["image"].reshape(1, -1, 3), b["image"]) and torch.equal(a["depth"].reshape(1, -1), b["depth"])
+        n = 3 * sc.W + 7                     # not a whole number of 4-row tile strips
+        c = model.render(ro[:1, :n], rd[:1, :n], staged=True, bg_color=1, perturb=False, frame_width=sc.W)
+        e = model.render(ro[:1, :n], rd[:1, :n], staged=True, bg_color=1, perturb=False)
+        assert torch.equal(c["image"], e["image"]) and torch.equal(c["depth"], e["depth"])
