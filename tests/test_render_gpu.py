@@ -176,7 +176,9 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
     try:
         # all shortcuts / no block jump / Morton-order probes / one reference iteration per launch / the frame-width hint (live
         # rays listed in 4x4-pixel tiles) on top of everything
-        for flags in (0, 1, 8, 256, "tiles"):
+        # ... / 4: no slow-ray grouping and 6: no coarse filter either -- the alive list stays in reference order and the last-iteration
+        # tensors are written slot-major WHILE launches cover several iterations (the combination of the bound >= 4 scenes)
+        for flags in (0, 1, 8, 256, 4, 6, "tiles"):
             lib.ngp_debug_disable_march_queue(0 if flags == "tiles" else flags)
             h = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(h.data_ptr())
@@ -189,7 +191,7 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
         lib.ngp_debug_set_sample_hash(None)
         lib.ngp_debug_disable_march_queue(0)
     assert sc.W % 4 == 0 and N % (4 * sc.W) == 0      # (the hint is only taken for whole rows of tiles)
-    for flags in (1, 8, 256, "tiles"):
+    for flags in (1, 8, 256, 4, 6, "tiles"):
         assert torch.equal(outs[0][0], outs[flags][0]), flags
         assert torch.equal(outs[0][1], outs[flags][1]), flags
         assert torch.equal(outs[0][3], outs[flags][3]) and torch.equal(outs[0][4], outs[flags][4]), flags   # last-iteration tensors
