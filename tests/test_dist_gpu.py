@@ -39,3 +39,12 @@ def test_two_ranks_on_one_gpu_render_the_same_images(device):
     assert s1["n_gpus"] == 1 and s2["n_gpus"] == 2 and s1["gathered"] == s2["gathered"] == [12, 640000, 3]
     assert one == two            # per-view sums of the fp16 bit patterns
     assert s1["checksum"] == s2["checksum"]
+
+
+def test_random_call_sequences_on_shared_contexts(device):
+    """scripts/fuzz_render_calls.py: 60 random render calls (ray counts 1..4096, step budgets, jitter, frame hints, bounds 1/2/4) on
+    three long-lived models: every call twice (bit-identical) and against the operator-by-operator loop.  State left behind by one
+    call must not reach the next (two such bugs were found this way)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_render_calls.py"), "5", "60"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "bad calls: 0" in out.stdout
