@@ -118,11 +118,13 @@ NGP_API int ngp_grid_encode_forward(const float* inputs, const void* embeddings,
 NGP_API int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
                              const int32_t* offsets_host, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                              uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
-                             void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream);
-
-/* The table gradient of large fp16 batches goes through a device workspace that ngp_grid_encode_backward grows on demand and
- * keeps (one per device; calls on different streams of one device must not overlap).  This frees it. */
-NGP_API int ngp_grid_encode_release_workspace(void);
+                             void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, void* workspace,
+                             size_t workspace_bytes, ngp_stream_t stream);
+/* The table gradient of large fp16 two-feature batches is a binned two-pass scatter through a CALLER-OWNED device workspace
+ * (nothing is kept between calls, so calls on different streams are independent).  ngp_grid_encode_backward_workspace returns
+ * the size that lets all levels go through the bins (0: this shape does not use one).  A smaller workspace makes the call process
+ * the levels in smaller groups; NULL falls back to one atomic per update -- same result up to the order of the atomics. */
+NGP_API size_t ngp_grid_encode_backward_workspace(uint32_t B, uint32_t D, uint32_t C, uint32_t L, int dtype);
 
 /* ---------------- _shencoder (shencoder/src/shencoder.h:10-13) ---------------- */
 
@@ -150,16 +152,18 @@ NGP_API int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights,
  * reference does not transfer the output activation either, ffmlp.cu:462-464).  backward_buffer [num_layers,B,hidden]:
  * slot j = dL/d(pre-activation) of forward_buffer[num_layers-1-j]; grad_weights (layout of `weights`) and, when
  * calc_grad_inputs, grad_inputs [B,input_dim] are overwritten.  Weight gradients are a deterministic split-K over the
- * batch: fp32 partials in a per-device workspace the library owns (grown on first use, released by
- * ngp_ffmlp_free_splitk) -- like the reference's split-K state it is shared, so do not run two backward calls
- * concurrently on different streams of one device.  Everything is enqueued on `stream`. */
+ * batch: fp32 partials in the CALLER's `workspace` (device memory, 16-byte aligned, ngp_ffmlp_backward_workspace(...) bytes;
+ * a smaller one -- at least one set of parameters, P * 4 bytes -- means fewer, longer batch chunks).  The library keeps no
+ * state between calls: unlike the reference's static split-K streams (ffmlp.cu:721-741) concurrent backward calls on
+ * different streams are independent.  Everything is enqueued on `stream`. */
 NGP_API int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
                        const uint16_t* forward_buffer, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                        int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
-                       uint16_t* grad_weights, ngp_stream_t stream);
-/* ffmlp.cu:721-741: the reference creates CUTLASS split-K streams/events here.  allocate is a no-op (the workspace is
- * sized by the first backward call); free releases the workspace. */
+                       uint16_t* grad_weights, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+NGP_API size_t ngp_ffmlp_backward_workspace(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
+/* ffmlp.cu:721-741: the reference creates CUTLASS split-K streams/events here.  Both are no-ops kept for the interface
+ * (ffmlp/ffmlp.py:126 calls allocate_splitk from FFMLP.__init__): this library has no split-K state of its own. */
 NGP_API int ngp_ffmlp_allocate_splitk(size_t n);
 NGP_API int ngp_ffmlp_free_splitk(void);
 
@@ -210,7 +214,14 @@ typedef struct ngp_model {
     uint32_t grid_size;           /* H (128)                                              */
     const void* cell_tables;      /* optional (may be NULL): per-cell corner records of the first cell_levels levels, */
     uint32_t cell_levels;         /* built by ngp_build_cell_tables; the fused kernels use the records when this is 12 */
+    const void* packed_weights;   /* the two blobs as MFMA fragments (ngp_pack_weights; ngp_packed_weights_bytes() bytes of device
+                                     memory, 16-byte aligned), packed once per parameter version.  Required by
+                                     ngp_network_forward / ngp_render_uniform; ngp_render_rays packs into its context when NULL */
 } ngp_model;
+
+/* fragment-major copy of model->sigma_weights / color_weights for the fused kernels (layout: render_fused.hip, k_pack_weights) */
+NGP_API size_t ngp_packed_weights_bytes(void);
+NGP_API int ngp_pack_weights(const ngp_model* model, void* out, ngp_stream_t stream);
 
 /* Per-cell corner records: a derived copy of the first n_levels levels of the hash table in which every grid CELL owns the 8
  * entries its corners map to (32 contiguous bytes), so that the fused kernels read one record per sample and level instead of
@@ -296,7 +307,11 @@ NGP_API int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n,
 NGP_API int ngp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
                   float beta2, float eps, uint32_t step, float grad_scale, ngp_stream_t stream);
 
-/* Diagnostics: when a device buffer of >= 16 uint64 is set, k_render_iter adds per-phase wave-cycle sums
+/* Diagnostics.  ngp_debug_set_stamps / ngp_debug_set_sample_hash / ngp_debug_disable_march_queue set the PROCESS DEFAULT;
+ * ngp_render_ctx_set_debug(ctx, 1, flags, stamps, sample_hash) gives one context its own state (enable = 0: back to the default).
+ * A render call snapshots the state that applies to it once, at its start: concurrent calls on other threads / streams are not
+ * affected by a change made while they run.
+ * When a device buffer of >= 16 uint64 is set, k_render_iter adds per-phase wave-cycle sums
  * (s_memtime deltas: [0] march, [1] encode+MLP tiles, [2] composite, [3] compaction+barrier; [4..6] march lane statistics; [8] encode + sigma net, [9] colour net, [10] tiles, [11] samples in them).  NULL (default) = no
  * stamp instruction executes. */
 NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
@@ -306,6 +321,7 @@ NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
  * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
+NGP_API int ngp_render_ctx_set_debug(ngp_render_ctx* ctx, int enable, int flags, unsigned long long* stamps, uint32_t* sample_hash);
 
 /* ---------------- per-kernel device timing (bench.py roofline leg) ---------------- */
 /* When enabled, selected kernels are bracketed by hipEvents on their own stream.

@@ -51,6 +51,8 @@ class FusedModel:
         self._cells = None
         self._cell_levels = 0
         self._cells_ready = False
+        self._packed = None      # the two weight blobs as MFMA fragments (ngp_pack_weights), packed with the cell tables
+        self.debug = None        # (flags, stamps tensor or None, sample-hash tensor or None): diagnostics state of THIS model's contexts
 
     # ---- construction from the two backbones ---------------------------------------------------------
     @classmethod
@@ -99,6 +101,7 @@ class FusedModel:
         m.cascade, m.grid_size = self.cascade, self.grid_size
         m.cell_tables = _lib.ptr(self._cells) if self._cells is not None else None
         m.cell_levels = self._cell_levels
+        m.packed_weights = _lib.ptr(self._packed) if self._packed is not None else None
         return m
 
     def _ensure_cells(self):
@@ -110,6 +113,9 @@ class FusedModel:
                 return
             lib = _lib.lib()
             m = self._struct(None)
+            packed = torch.empty(lib.ngp_packed_weights_bytes(), dtype=torch.uint8, device=self.device)
+            _lib.check(lib.ngp_pack_weights(C.byref(m), _lib.ptr(packed), _lib.stream()), "pack_weights")
+            self._packed = packed
             free, _ = torch.cuda.mem_get_info(self.device)
             budget = min(self.cell_table_gb * (1 << 30), free / 3)
             for n in (12,):          # (the kernels are specialised for exactly twelve expanded levels)
@@ -117,9 +123,9 @@ class FusedModel:
                 if 0 < nbytes <= budget:
                     cells = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
                     _lib.check(lib.ngp_build_cell_tables(C.byref(m), n, _lib.ptr(cells), _lib.stream()), "build_cell_tables")
-                    torch.cuda.current_stream(self.device).synchronize()   # other streams may render with it next
                     self._cells, self._cell_levels = cells, n
                     break
+            torch.cuda.current_stream(self.device).synchronize()   # other streams may render with the derived copies next
             self._cells_ready = True
 
     def network_forward(self, xyzs, dirs):
@@ -183,6 +189,9 @@ class FusedModel:
         ctx = self._context(N)
         need_stats = want_stats or want_last
         _lib.check(lib.ngp_render_ctx_set_frame_width(ctx, int(frame_width or 0)), "render_ctx_set_frame_width")
+        if self.debug is not None:
+            flags, stamps, hashes = self.debug
+            _lib.check(lib.ngp_render_ctx_set_debug(ctx, 1, int(flags), _lib.ptr(stamps), _lib.ptr(hashes)), "render_ctx_set_debug")
         _lib.check(lib.ngp_render_rays(ctx, C.byref(m), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()),
                                        _lib.ptr(fars.contiguous()), N, float(dt_gamma), int(max_steps), int(perturb), _lib.ptr(weights_sum),
                                        _lib.ptr(depth), _lib.ptr(image), _lib.ptr(last_s), _lib.ptr(last_c),

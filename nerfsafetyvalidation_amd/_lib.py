@@ -26,7 +26,7 @@ class ModelStruct(C.Structure):
         ("embeddings", _vp), ("offsets_host", _vp), ("L", _u32), ("S", _f32), ("H_base", _u32), ("gridtype", _u32),
         ("align_corners", _int), ("sigma_weights", _vp), ("sigma_hidden_mm", _u32), ("color_weights", _vp),
         ("color_hidden_mm", _u32), ("bound", _f32), ("density_scale", _f32), ("density_bitfield", _vp),
-        ("cascade", _u32), ("grid_size", _u32), ("cell_tables", _vp), ("cell_levels", _u32),
+        ("cascade", _u32), ("grid_size", _u32), ("cell_tables", _vp), ("cell_levels", _u32), ("packed_weights", _vp),
     ]
 
 
@@ -57,13 +57,14 @@ SIGNATURES = {
     "ngp_composite_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ngp_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int, _int, _vp],
     "ngp_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _u32, _int,
-                                 _int, _vp],
-    "ngp_grid_encode_release_workspace": [],
+                                 _int, _vp, _sz, _vp],
+    "ngp_grid_encode_backward_workspace": [_u32, _u32, _u32, _u32, _int],
     "ngp_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _int, _vp, _vp],
     "ngp_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
     "ngp_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "ngp_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
-    "ngp_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp, _vp],
+    "ngp_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp, _vp, _sz, _vp],
+    "ngp_ffmlp_backward_workspace": [_u32, _u32, _u32, _u32],
     "ngp_ffmlp_allocate_splitk": [_sz],
     "ngp_ffmlp_free_splitk": [],
     "ngp_get_rays": [_vp, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _u32, _vp, _vp, _vp],
@@ -73,6 +74,8 @@ SIGNATURES = {
     "ngp_adam_step": [_vp, _vp, _vp, _vp, C.c_uint64, _f32, _f32, _f32, _f32, _u32, _f32, _vp],
     "ngp_cell_tables_bytes": [C.POINTER(ModelStruct), _u32],
     "ngp_build_cell_tables": [C.POINTER(ModelStruct), _u32, _vp, _vp],
+    "ngp_packed_weights_bytes": [],
+    "ngp_pack_weights": [C.POINTER(ModelStruct), _vp, _vp],
     "ngp_render_ctx_create": [_u32, C.POINTER(_vp)],
     "ngp_render_ctx_destroy": [_vp],
     "ngp_render_ctx_set_frame_width": [_vp, _u32],
@@ -83,11 +86,13 @@ SIGNATURES = {
     "ngp_debug_set_stamps": [_vp],
     "ngp_debug_set_sample_hash": [_vp],
     "ngp_debug_disable_march_queue": [_int],
+    "ngp_render_ctx_set_debug": [_vp, _int, _int, _vp, _vp],
     "ngp_prof_enable": [_int],
     "ngp_prof_reset": [],
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
-_RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
+_RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
+             "ngp_ffmlp_backward_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
 
 _lib = None
 

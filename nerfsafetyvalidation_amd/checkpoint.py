@@ -13,8 +13,22 @@ import os
 import torch
 
 
+def _inert_numpy_globals():
+    """The pickled globals of a numpy SCALAR: Trainer.save_checkpoint stores `stats` with PSNRMeter.measure() values (V / N with V a
+    numpy.float64, nerf/utils.py:212,923,980), which the weights-only unpickler rejects by default.  These three rebuild a scalar
+    from raw bytes and execute nothing from the file."""
+    import numpy as np
+    try:
+        from numpy._core.multiarray import scalar          # numpy >= 2
+    except ImportError:                                     # numpy 1.x
+        from numpy.core.multiarray import scalar
+    return [scalar, np.dtype] + sorted({type(np.dtype(t)) for t in ("float64", "float32", "int64", "int32", "bool")}, key=repr)
+
+
 def _read(path, map_location="cpu"):
-    return torch.load(path, map_location=map_location, weights_only=True)
+    """weights-only load (nothing in the file is executed) with the inert numpy-scalar globals allow-listed"""
+    with torch.serialization.safe_globals(_inert_numpy_globals()):
+        return torch.load(path, map_location=map_location, weights_only=True)
 
 
 def latest_checkpoint(ckpt_path, name="ngp"):

@@ -28,6 +28,19 @@ int check_launch(const char* what) {
     return NGP_OK;
 }
 
+static std::mutex g_attr_mu;
+static std::vector<std::pair<int, const void*>> g_attr_done;
+
+void ensure_dynamic_lds(const void* func, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    for (const auto& e : g_attr_done)
+        if (e.first == dev && e.second == func) return;
+    (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    g_attr_done.emplace_back(dev, func);
+}
+
 // ---- profiling: events around selected launches, only when enabled -------------
 struct ProfEntry {
     std::string name;

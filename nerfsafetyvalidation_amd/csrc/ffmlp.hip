@@ -272,12 +272,8 @@ template <int HB, int R>
 static void launch_ffmlp_lds(const uint16_t* in, const uint16_t* w, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                              uint32_t out_act, uint16_t* fwd, uint16_t* out, hipStream_t s) {
     const size_t lds = ffmlp_lds_halves(in_dim, HB * 16, num_layers) * sizeof(_Float16);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_ffmlp_forward_lds<HB, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfmlpLdsMax);
-        (void)hipFuncSetAttribute((const void*)k_ffmlp_forward_lds<HB, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfmlpLdsMax);
-        attr = true;
-    }
+    ensure_dynamic_lds((const void*)k_ffmlp_forward_lds<HB, R, true>, (int)kFfmlpLdsMax);
+    ensure_dynamic_lds((const void*)k_ffmlp_forward_lds<HB, R, false>, (int)kFfmlpLdsMax);
     const uint32_t n_groups = div_up(B / 16, (uint32_t)R);
     uint32_t blocks = div_up(n_groups, 4);
     if (blocks > 256 * 2) blocks = 256 * 2;   // two resident workgroups per CU, grid-stride beyond that
@@ -623,38 +619,19 @@ __global__ void __launch_bounds__(64 * kReduceWaves) k_ffmlp_bwd_reduce(const fl
     }
 }
 
-// fp32 split-K workspace, one per device, grown on demand (the reference's counterpart is the CUTLASS
-// workspace behind allocate_splitk/free_splitk, ffmlp.cu:711-741)
-static std::mutex g_ws_mu;
-static float* g_ws[32] = {};
-static size_t g_ws_bytes[32] = {};
-
-static float* splitk_workspace(size_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    if (g_ws_bytes[dev] < bytes) {
-        if (g_ws[dev]) (void)hipFree(g_ws[dev]);  // hipFree waits for work that still uses it
-        g_ws[dev] = nullptr;
-        g_ws_bytes[dev] = 0;
-        if (hipMalloc((void**)&g_ws[dev], bytes) != hipSuccess) return nullptr;
-        g_ws_bytes[dev] = bytes;
-    }
-    return g_ws[dev];
+// batch split of the weight-gradient contraction: ~256 rows per chunk, at most 1024 chunks / 256 MB of fp32 partials, and
+// no more chunks than the caller's workspace holds.  Returns the chunk length in rows (a multiple of 16) and the chunk count.
+static uint32_t splitk_plan(uint32_t B, uint32_t P, size_t workspace_bytes, uint32_t& S) {
+    S = B / 256 ? B / 256 : 1;
+    if (S > 1024) S = 1024;
+    const size_t cap = workspace_bytes / ((size_t)P * 4);
+    if (S > cap) S = cap ? (uint32_t)cap : 1;
+    const uint32_t chunk = div_up(div_up(B, S), 16) * 16;
+    S = div_up(B, chunk);
+    return chunk;
 }
-
-static void splitk_release() {
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    for (int d = 0; d < 32; d++)
-        if (g_ws[d]) {
-            (void)hipSetDevice(d);
-            (void)hipFree(g_ws[d]);
-            g_ws[d] = nullptr;
-            g_ws_bytes[d] = 0;
-        }
-    (void)hipSetDevice(cur);
+static uint32_t ffmlp_params(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    return hidden_dim * (input_dim + (num_layers - 1) * hidden_dim + 16);
 }
 
 template <int HB, int TPW>
@@ -666,12 +643,7 @@ static void launch_bwd_chain(const uint16_t* grad, const uint16_t* w, const uint
     const size_t one = (size_t)HID * (SH > sIn || !gi ? SH : sIn) * 2;
     const uint32_t resident = all <= 64 * 1024 ? 1 : 0;  // 2 workgroups per CU keep their weights; larger nets stream per layer
     const size_t lds = resident ? all : one;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffmlp_bwd_chain<HB, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_ffmlp_bwd_chain<HB, TPW>), 160 * 1024);
     const uint32_t n_tiles = B / 16, n_groups = div_up(n_tiles, 4 * TPW);
     const uint32_t per_cu = lds <= 32 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
     uint32_t blocks = n_groups < 256 * per_cu ? n_groups : 256 * per_cu;
@@ -704,7 +676,7 @@ int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
 int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer, uint32_t B,
                        uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                        uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
-                       uint16_t* grad_weights, ngp_stream_t stream) {
+                       uint16_t* grad_weights, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
     (void)output_activation;  // not transferred by the reference either (ffmlp.cu:462-464); FFMLP always passes `none`
     if (B == 0) return NGP_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -717,16 +689,13 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
     NGP_REQUIRE(hidden_dim == 16 || hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128 || hidden_dim == 256,
                 "FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got %u", hidden_dim);
     uint16_t* gi = calc_grad_inputs ? grad_inputs : nullptr;
-    const uint32_t P = hidden_dim * (input_dim + (num_layers - 1) * hidden_dim + 16);
-    // batch split of the weight-gradient contraction: ~256 rows per chunk, at most 1024 chunks / 256 MB of partials
-    uint32_t S = B / 256 ? B / 256 : 1;
-    if (S > 1024) S = 1024;
-    const size_t cap = ((size_t)256 << 20) / ((size_t)P * 4);
-    if (S > cap) S = cap ? (uint32_t)cap : 1;
-    const uint32_t chunk = div_up(div_up(B, S), 16) * 16;
-    S = div_up(B, chunk);
-    float* ws = splitk_workspace((size_t)S * P * 4);
-    NGP_REQUIRE(ws, "ffmlp_backward: cannot allocate %zu bytes of split-K workspace", (size_t)S * P * 4);
+    const uint32_t P = ffmlp_params(input_dim, hidden_dim, num_layers);
+    NGP_REQUIRE(workspace && workspace_bytes >= (size_t)P * 4 && ((uintptr_t)workspace & 15) == 0,
+                "ffmlp_backward: split-K workspace missing, misaligned or smaller than one set of partials (%zu < %zu bytes); "
+                "ngp_ffmlp_backward_workspace() gives the size", workspace_bytes, (size_t)P * 4);
+    uint32_t S;
+    const uint32_t chunk = splitk_plan(B, P, workspace_bytes, S);
+    float* ws = reinterpret_cast<float*>(workspace);
     ProfScope prof("ffmlp_backward", s, B);
     switch (hidden_dim) {
         case 16: launch_bwd_chain<1, 4>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
@@ -747,9 +716,16 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
     return check_launch("ffmlp_backward (split-K reduction)");
 }
 
-// The reference creates its split-K side streams here (ffmlp.cu:721-741); this library's split-K workspace is
-// allocated on first use, so allocate is a no-op and free releases the workspace.
+size_t ngp_ffmlp_backward_workspace(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    const uint32_t P = ffmlp_params(input_dim, hidden_dim, num_layers);
+    uint32_t S;
+    (void)splitk_plan(B ? B : 16, P, (size_t)256 << 20, S);
+    return (size_t)S * P * 4;
+}
+
+// The reference creates its CUTLASS split-K side streams and events here (ffmlp.cu:721-741).  This library keeps no state
+// between calls -- the split-K partials live in the caller's workspace -- so both are no-ops kept for the interface.
 int ngp_ffmlp_allocate_splitk(size_t n) { (void)n; return NGP_OK; }
-int ngp_ffmlp_free_splitk(void) { splitk_release(); return NGP_OK; }
+int ngp_ffmlp_free_splitk(void) { return NGP_OK; }
 
 }  // extern "C"

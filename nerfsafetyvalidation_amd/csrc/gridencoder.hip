@@ -483,37 +483,8 @@ __global__ void __launch_bounds__(256) k_grid_bwd_bin_reduce(const uint2* __rest
     }
 }
 
-// workspace of the binned scatter: grown on demand, one per device, reused by every call (calls on different streams of one
-// device must not overlap; ngp_grid_encode_release_workspace frees it)
-static std::mutex g_bin_mu;
-static void* g_bin_ws[32] = {};
-static size_t g_bin_bytes[32] = {};
-static void* bin_workspace(size_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    std::lock_guard<std::mutex> lk(g_bin_mu);
-    if (g_bin_bytes[dev] < bytes) {
-        if (g_bin_ws[dev]) (void)hipFree(g_bin_ws[dev]);   // hipFree waits for work that still uses it
-        g_bin_ws[dev] = nullptr;
-        g_bin_bytes[dev] = 0;
-        if (hipMalloc(&g_bin_ws[dev], bytes) != hipSuccess) return nullptr;
-        g_bin_bytes[dev] = bytes;
-    }
-    return g_bin_ws[dev];
-}
-static void bin_release() {
-    std::lock_guard<std::mutex> lk(g_bin_mu);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    for (int d = 0; d < 32; d++)
-        if (g_bin_ws[d]) {
-            (void)hipSetDevice(d);
-            (void)hipFree(g_bin_ws[d]);
-            g_bin_ws[d] = nullptr;
-            g_bin_bytes[d] = 0;
-        }
-    (void)hipSetDevice(cur);
-}
+// workspace of the binned scatter: the caller's (ngp_grid_encode_backward_workspace gives the size that lets every level of a
+// group go through the bins in one pass; with less, the levels are processed in smaller groups, with none they use atomics)
 constexpr size_t kBinWorkspaceMax = (size_t)4 << 30;    // levels are processed in groups that fit this
 static bool bin_off() {                                  // diagnostics (NGP_GRID_NO_BINS set): atomics for every level
     static const bool off = getenv("NGP_GRID_NO_BINS") != nullptr;
@@ -580,7 +551,8 @@ static void launch_forward(const float* inputs, const void* emb, void* out, uint
 
 template <typename T, int D, int C>
 static void launch_backward(const void* grad, const float* inputs, void* grad_emb, uint32_t B, uint32_t L, const GridLevels& lv, bool gi,
-                            const void* dy_dx, void* grad_inputs, uint32_t gridtype, bool ac, hipStream_t s) {
+                            const void* dy_dx, void* grad_inputs, uint32_t gridtype, bool ac, void* workspace, size_t workspace_bytes,
+                            hipStream_t s) {
     const uint32_t nb = div_up(B, kGridBlock);
     if (!grad_emb) {   // frozen table (the rollout's pose gradients): only the input gradient
         if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
@@ -598,12 +570,8 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         }
     }
     if (n_small) {
-        static bool attr[4][9] = {};
         auto kern = k_grid_backward_small<T, D, C>;
-        if (!attr[D][C]) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSmallMaxFloats * sizeof(float)));
-            attr[D][C] = true;
-        }
+        ensure_dynamic_lds((const void*)kern, (int)(kSmallMaxFloats * sizeof(float)));
         const uint32_t n_pb = div_up(B, (uint32_t)kSmallThreads);
         const uint32_t bx = n_pb < 256u ? n_pb : 256u;
         kern<<<dim3(bx, n_small), kSmallThreads, lds, s>>>((const T*)grad, inputs, (T*)grad_emb, B, lv, gridtype, ac, small_mask);
@@ -618,16 +586,13 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
                 if (!((small_mask >> l) & 1u) && lv.offset[l + 1] - lv.offset[l] <= kBinMax * kBinEntries) bl.level[n_bin++] = l;
         const uint32_t n_pb = div_up(B, kBinPoints);
         const size_t per_level = (size_t)n_pb * kBinMax * (kBinCap * sizeof(uint2) + sizeof(uint32_t));
-        uint32_t group = n_bin ? (uint32_t)(kBinWorkspaceMax / per_level) : 0;
+        const size_t usable = workspace ? (workspace_bytes < kBinWorkspaceMax ? workspace_bytes : kBinWorkspaceMax) : 0;
+        uint32_t group = n_bin ? (uint32_t)(usable / per_level) : 0;
         group = group < n_bin ? group : n_bin;
-        char* ws = group ? (char*)bin_workspace(per_level * group) : nullptr;
+        char* ws = group ? (char*)workspace : nullptr;
         if (ws) {
-            static bool attr = false;
             const size_t lds_bin = (size_t)kBinMax * kBinCap * sizeof(uint2) + kBinMax * sizeof(uint32_t);
-            if (!attr) {
-                (void)hipFuncSetAttribute((const void*)k_grid_bwd_bin<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin);
-                attr = true;
-            }
+            ensure_dynamic_lds((const void*)k_grid_bwd_bin<D>, (int)lds_bin);
             uint2* records = reinterpret_cast<uint2*>(ws);
             uint32_t* counts = reinterpret_cast<uint32_t*>(ws + (size_t)group * n_pb * kBinMax * kBinCap * sizeof(uint2));
             for (uint32_t first = 0; first < n_bin; first += group) {
@@ -698,7 +663,7 @@ int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const i
 int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets_host,
                              void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int dtype,
-                             ngp_stream_t stream) {
+                             void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
     (void)embeddings;
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(grad && inputs && offsets_host, "grid_encode_backward: null pointer");
@@ -715,24 +680,31 @@ int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* 
     ProfScope prof("grid_encode_backward", s, B);
     const bool gi = calc_grad_inputs != 0, ac = align_corners != 0;
     if (dtype == NGP_F32) {
-        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s)
+        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace,
+                        workspace_bytes, s)
     } else {
         switch (D * 16 + C) {
-            case 2 * 16 + 2: launch_backward<_Float16, 2, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
-            case 2 * 16 + 4: launch_backward<_Float16, 2, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
-            case 2 * 16 + 8: launch_backward<_Float16, 2, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
-            case 3 * 16 + 2: launch_backward<_Float16, 3, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
-            case 3 * 16 + 4: launch_backward<_Float16, 3, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
-            case 3 * 16 + 8: launch_backward<_Float16, 3, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, s); break;
+            case 2 * 16 + 2: launch_backward<_Float16, 2, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
+            case 2 * 16 + 4: launch_backward<_Float16, 2, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
+            case 2 * 16 + 8: launch_backward<_Float16, 2, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
+            case 3 * 16 + 2: launch_backward<_Float16, 3, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
+            case 3 * 16 + 4: launch_backward<_Float16, 3, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
+            case 3 * 16 + 8: launch_backward<_Float16, 3, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
             default: break;
         }
     }
     return check_launch("grid_encode_backward");
 }
 
-int ngp_grid_encode_release_workspace(void) {
-    bin_release();
-    return NGP_OK;
+size_t ngp_grid_encode_backward_workspace(uint32_t B, uint32_t D, uint32_t C, uint32_t L, int dtype) {
+    // only the binned scatter of an fp16, two-feature table on a large batch uses it (launch_backward)
+    (void)D;
+    if (dtype != NGP_F16 || C != 2 || B < 128u * 1024u || bin_off()) return 0;
+    const size_t per_level = (size_t)div_up(B, kBinPoints) * kBinMax * (kBinCap * sizeof(uint2) + sizeof(uint32_t));
+    const size_t all = per_level * L;
+    if (all <= kBinWorkspaceMax) return all;
+    const size_t group = kBinWorkspaceMax / per_level;
+    return group ? group * per_level : 0;
 }
 
 }  // extern "C"

@@ -37,6 +37,11 @@ void prof_add_units(const char* name, double units);
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(..., hipFuncAttributeMaxDynamicSharedMemorySize, bytes), once per (device, kernel): the attribute belongs to
+// the kernel's code object on ONE device, and render calls arrive from several host threads (pipeline.py) -- a plain
+// `static bool` guard is neither per device nor safe to race on.
+void ensure_dynamic_lds(const void* func, int bytes);
+
 // ---- hash-grid level geometry, evaluated once per call on the host -----------------
 // scale / resolution exactly as gridencoder.cu:126-128; the index recipe of get_grid_index
 // (gridencoder.cu:54-72) is folded into per-level multipliers so that the device code does

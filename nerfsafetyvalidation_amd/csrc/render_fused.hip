@@ -34,6 +34,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "ngp_common.hpp"
 
 namespace ngp {
@@ -104,6 +106,7 @@ struct NetArgs {
     const uint4* cells;
     uint32_t cell_steps;
     uint32_t cell_off[16];     // first record of a level
+    uint32_t dbg_shrink;       // diagnostics (debug flag bits 4-7): fold hashed levels into size >> n entries (timing only, wrong images)
 };
 
 __host__ __device__ inline uint32_t sig_halfs(uint32_t mm) { return 2048 + mm * 4096 + 1024; }
@@ -446,7 +449,6 @@ __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds
 }
 
 // stage packed weights + level table into LDS (all threads of the block)
-__device__ uint32_t d_dbg_shrink = 0;  // diagnostics (ngp_debug_disable_march_queue bits 4-7): fold hashed levels into size >> n entries
 __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels& lv, _Float16* Wlds, LevelTab* lt) {
     const uint32_t n16 = (sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) / 8;  // 16-byte chunks
     const uint4* src = reinterpret_cast<const uint4*>(na.packed);
@@ -460,7 +462,7 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
         lt->size[l] = size;
         lt->a1[l] = lv.hashed[l] ? 2654435761u : lv.mul1[l];
         lt->a2[l] = lv.hashed[l] ? 805459861u : lv.mul2[l];
-        lt->mask[l] = lv.mode[l] == 1 ? (size >> d_dbg_shrink) - 1 : 0xFFFFFFFFu;
+        lt->mask[l] = lv.mode[l] == 1 ? (size >> na.dbg_shrink) - 1 : 0xFFFFFFFFu;
         lt->flags[l] = (uint32_t)lv.hashed[l] | (lv.mode[l] == 2 ? 2u : 0u);
         lt->cell_off[l] = na.cell_off[l];
         lt->cell_res[l] = lv.resolution[l];
@@ -1317,17 +1319,39 @@ struct ngp_render_ctx {
     uint32_t seq_base = 0;       // sequence numbers already used by earlier render calls (slots are matched by number)
     hipEvent_t ev[kRing];
     int num_cu = 256;
+    bool has_debug = false;      // ngp_render_ctx_set_debug: this context's own diagnostics state (else the process default)
+    int debug_flags = 0;
+    unsigned long long* debug_stamps = nullptr;
+    uint32_t* debug_sample_hash = nullptr;
 };
 
-static unsigned long long* g_stamps = nullptr;
-static uint32_t* g_sample_hash = nullptr;
-static bool g_coarse_off = false;
-static bool g_lin_off = false;
-static bool g_jump_off = false;
-static bool g_spec_off = false;
-static bool g_tile_off = false;         // bit 13 of the debug flags: ignore the frame-width hint
-static uint32_t g_spec_safety_x2 = 0;   // 0: kSpecSafetyX2
-static bool g_sort_off = false;
+// Diagnostics state.  The process-wide setters (ngp_debug_*) only change the DEFAULT; a context can carry its own
+// (ngp_render_ctx_set_debug), and every render call takes ONE snapshot when it starts, so concurrent calls on other host threads /
+// streams (pipeline.py) never see a half-changed set and never change under a running call.
+struct DebugState {
+    int flags = 0;
+    unsigned long long* stamps = nullptr;
+    uint32_t* sample_hash = nullptr;
+    bool coarse_off() const { return (flags & 2) != 0; }
+    bool sort_off() const { return (flags & 4) != 0; }
+    bool lin_off() const { return (flags & 8) != 0; }
+    bool jump_off() const { return (flags & 1) != 0; }
+    bool spec_off() const { return (flags & 256) != 0; }
+    bool tile_off() const { return (flags & 8192) != 0; }
+    uint32_t spec_safety_x2() const { return ((uint32_t)flags >> 9) & 15u; }   // 0: kSpecSafetyX2
+    uint32_t shrink() const { return ((uint32_t)flags >> 4) & 15u; }
+};
+static std::mutex g_debug_mu;
+static DebugState g_debug_default;
+static DebugState debug_snapshot(const ngp_render_ctx* ctx) {
+    if (ctx && ctx->has_debug) {
+        DebugState d;
+        d.flags = ctx->debug_flags; d.stamps = ctx->debug_stamps; d.sample_hash = ctx->debug_sample_hash;
+        return d;
+    }
+    std::lock_guard<std::mutex> lk(g_debug_mu);
+    return g_debug_default;
+}
 
 // per-cell corner records: record r of level l (cells x-fastest, `res` per axis) = the table entries of the cell's 8 corners in
 // the gather's corner order (bit 0 of the corner index = x).  One thread per record.
@@ -1371,12 +1395,11 @@ static bool needs_generic(const GridLevels& lv) {
     return false;
 }
 
-static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* packed, NetArgs& na, GridLevels& lv) {
+static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* packed, NetArgs& na, GridLevels& lv) {
     NGP_REQUIRE(m && m->embeddings && m->offsets_host && m->sigma_weights && m->color_weights, "ngp_model: null pointer");
     NGP_REQUIRE(m->L == 16, "fused renderer: the hash grid must have 16 levels with 2 features (got L=%u)", m->L);
     NGP_REQUIRE(m->sigma_hidden_mm <= 2 && m->color_hidden_mm <= 3, "fused renderer: at most 2 / 3 hidden matmuls (got %u / %u)",
                 m->sigma_hidden_mm, m->color_hidden_mm);
-    (void)ctx;
     fill_levels(lv, m->offsets_host, 16, m->S, m->H_base, 3, m->gridtype, m->align_corners != 0);
     na.table = reinterpret_cast<const uint32_t*>(m->embeddings);
     na.packed = packed;
@@ -1386,6 +1409,7 @@ static int fill_net(const ngp_model* m, const ngp_render_ctx* ctx, _Float16* pac
     na.inv_two_bound = 1.0f / (2 * m->bound);
     na.density_scale = m->density_scale;
     na.align_corners = m->align_corners;
+    na.dbg_shrink = dbg.shrink();
     na.cells = nullptr;
     na.cell_steps = 0;
     for (int l = 0; l < 16; l++) na.cell_off[l] = 0;
@@ -1496,24 +1520,29 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     NGP_REQUIRE(model->cascade >= 1 && model->cascade <= 8 && model->grid_size >= 2 && model->grid_size <= 1024,
                 "render_rays: unsupported cascade/grid size");
     hipStream_t s = (hipStream_t)stream;
+    const DebugState dbg = debug_snapshot(ctx);   // ONE snapshot per call (see DebugState)
     NetArgs na;
     GridLevels lv;
-    int rc = fill_net(model, ctx, ctx->packed, na, lv);
+    // fragment-major weights: the model's own (ngp_pack_weights, packed once per parameter version) or, without them, packed into
+    // this context's buffer now
+    const _Float16* packed = model && model->packed_weights ? (const _Float16*)model->packed_weights : ctx->packed;
+    int rc = fill_net(model, dbg, packed, na, lv);
     if (rc) return rc;
-
-    const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
-    k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
-                                                         (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
+    if (!model->packed_weights) {
+        const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
+        k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
+                                                             (const _Float16*)model->color_weights, na.col_mm, ctx->packed);
+    }
     // several reference iterations per launch (see Ctl): not with jitter
     // bit 0: launches may cover several reference iterations; bit 1: but never the last one (its tensors are wanted); bits 8..: diagnostics
-    const uint32_t spec_allowed = (!g_spec_off && perturb == 0) ? (1u | (last_sigmas ? 2u : 0u) | (g_spec_safety_x2 << 8)) : 0u;
+    const uint32_t spec_allowed = (!dbg.spec_off() && perturb == 0) ? (1u | (last_sigmas ? 2u : 0u) | (dbg.spec_safety_x2() << 8)) : 0u;
     // scheduling hint (ngp_render_ctx_set_frame_width): whole rows of 4x4-pixel tiles only; not with jitter (seeded with the list index)
     const uint32_t fw = ctx->frame_width;
-    const uint32_t tile_w = (perturb == 0 && !g_tile_off && fw >= 4 && fw % 4 == 0 && N % (4 * fw) == 0) ? fw : 0u;
+    const uint32_t tile_w = (perturb == 0 && !dbg.tile_off() && fw >= 4 && fw % 4 == 0 && N % (4 * fw) == 0) ? fw : 0u;
     // (the grid also has to cover the loop's own counters -- both death-count buffers -- however few rays there are)
     const uint32_t init_threads = N > 2u * kDeathShards * kSpecK ? N : 2u * kDeathShards * kSpecK;
     k_render_init<<<div_up(init_threads, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
-                                                 g_sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed, tile_w);
+                                                 dbg.sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed, tile_w);
 
     RenderArgs ra = {};
     ra.rays_o = rays_o; ra.rays_d = rays_d; ra.fars = fars; ra.rays_t = ctx->rays_t;
@@ -1525,19 +1554,19 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
-    ra.stamps = g_stamps;
-    ra.sort_slow = (perturb == 0 && !g_sort_off) ? 1u : 0u;   // needs the coarse filter; checked below
-    ra.sample_hash = g_sample_hash;
+    ra.stamps = dbg.stamps;
+    ra.sort_slow = (perturb == 0 && !dbg.sort_off()) ? 1u : 0u;   // needs the coarse filter; checked below
+    ra.sample_hash = dbg.sample_hash;
 
     // coarse occupancy filter: usable when the bitfield is 8-byte aligned and its 1:64 reduction fits the LDS budget
     const size_t cells = (size_t)model->cascade * model->grid_size * model->grid_size * model->grid_size;
     const size_t coarse_bytes = cells / 64 / 8;
-    const bool use_coarse = !g_coarse_off && cells % 4096 == 0 && coarse_bytes <= kCoarseMaxBytes && ((uintptr_t)model->density_bitfield & 7) == 0;
+    const bool use_coarse = !dbg.coarse_off() && cells % 4096 == 0 && coarse_bytes <= kCoarseMaxBytes && ((uintptr_t)model->density_bitfield & 7) == 0;
     // linear re-layout (cheaper DDA probes): power-of-two grid of at least 8^3 cells; bit 3 of the debug flags turns it off
     const uint32_t Hg = model->grid_size;
     uint32_t logH = 0;
     while ((1u << logH) < Hg) logH++;
-    bool lin = use_coarse && !g_lin_off && (1u << logH) == Hg && Hg >= 8 && cells / 8 <= kLinMaxBytes;
+    bool lin = use_coarse && !dbg.lin_off() && (1u << logH) == Hg && Hg >= 8 && cells / 8 <= kLinMaxBytes;
     if (lin && !ctx->grid_lin && hipMalloc(&ctx->grid_lin, kLinMaxBytes) != hipSuccess) lin = false;
     if (lin) {
         const uint32_t n_words = (uint32_t)(cells / 32), n_coarse = (uint32_t)(cells / 64);
@@ -1548,7 +1577,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.coarse_words = (uint32_t)(coarse_bytes / 4);
         ra.bitfield_lin = ctx->grid_lin;
         ra.log_grid = logH;
-        ra.block_jump = g_jump_off ? 0u : 1u;
+        ra.block_jump = dbg.jump_off() ? 0u : 1u;
     } else if (use_coarse) {
         const uint32_t n_words = (uint32_t)(cells / 64);
         k_build_coarse<<<div_up(n_words, 256), 256, 0, s>>>((const unsigned long long*)model->density_bitfield, n_words, ctx->coarse);
@@ -1572,16 +1601,12 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     }
     const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab) + (use_coarse ? coarse_bytes : 0);
     const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_iter<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<0, false>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<1, false>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<2, false>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<0, true>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<1, true>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<2, true>), 160 * 1024);
     const bool generic = needs_generic(lv);
     const bool use_cells = na.cells != nullptr;
     NGP_REQUIRE(lds <= 160 * 1024, "render_rays: LDS budget exceeded (%zu bytes)", lds);
@@ -1614,7 +1639,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
                                                            ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1,
                                                            ctx->death_shards + (size_t)cur * kDeathShards * kSpecK, spec_allowed, ctx->alive[cur],
-                                                           ctx->backup, ctx->rays_t, weights_sum, depth, image, g_sample_hash, ctx->stat_shards,
+                                                           ctx->backup, ctx->rays_t, weights_sum, depth, image, dbg.sample_hash, ctx->stat_shards,
                                                            ctx->death_shards + (size_t)(cur ^ 1) * kDeathShards * kSpecK);
         launched++;
         launches += 2;
@@ -1688,26 +1713,44 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
 }
 
 int ngp_debug_set_stamps(unsigned long long* device_buf) {
-    g_stamps = device_buf;
+    std::lock_guard<std::mutex> lk(g_debug_mu);
+    g_debug_default.stamps = device_buf;
     return NGP_OK;
 }
 
 int ngp_debug_set_sample_hash(uint32_t* device_buf) {
-    g_sample_hash = device_buf;
+    std::lock_guard<std::mutex> lk(g_debug_mu);
+    g_debug_default.sample_hash = device_buf;
     return NGP_OK;
 }
 
 int ngp_debug_disable_march_queue(int off) {
-    g_coarse_off = (off & 2) != 0;
-    g_sort_off = (off & 4) != 0;
-    g_lin_off = (off & 8) != 0;
-    g_jump_off = (off & 1) != 0;
-    g_spec_off = (off & 256) != 0;
-    g_spec_safety_x2 = ((uint32_t)off >> 9) & 15u;
-    g_tile_off = (off & 8192) != 0;
-    const uint32_t sh = (uint32_t)(off >> 4) & 15u;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(d_dbg_shrink), &sh, 4);
+    std::lock_guard<std::mutex> lk(g_debug_mu);
+    g_debug_default.flags = off;
     return NGP_OK;
+}
+
+int ngp_render_ctx_set_debug(ngp_render_ctx* ctx, int enable, int flags, unsigned long long* stamps, uint32_t* sample_hash) {
+    NGP_REQUIRE(ctx, "render_ctx_set_debug: null context");
+    ctx->has_debug = enable != 0;
+    ctx->debug_flags = flags;
+    ctx->debug_stamps = stamps;
+    ctx->debug_sample_hash = sample_hash;
+    return NGP_OK;
+}
+
+size_t ngp_packed_weights_bytes(void) { return (size_t)(sig_halfs(2) + sig_halfs(3)) * 2; }
+
+int ngp_pack_weights(const ngp_model* model, void* out, ngp_stream_t stream) {
+    NGP_REQUIRE(model && model->sigma_weights && model->color_weights && out, "pack_weights: null pointer");
+    NGP_REQUIRE(model->sigma_hidden_mm <= 2 && model->color_hidden_mm <= 3, "pack_weights: at most 2 / 3 hidden matmuls (got %u / %u)",
+                model->sigma_hidden_mm, model->color_hidden_mm);
+    NGP_REQUIRE(((uintptr_t)out & 15) == 0, "pack_weights: the buffer must be 16-byte aligned");
+    const uint32_t n_packed = sig_halfs(model->sigma_hidden_mm) + sig_halfs(model->color_hidden_mm);
+    k_pack_weights<<<div_up(n_packed, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)model->sigma_weights, model->sigma_hidden_mm,
+                                                                           (const _Float16*)model->color_weights, model->color_hidden_mm,
+                                                                           (_Float16*)out);
+    return check_launch("pack_weights");
 }
 
 int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N,
@@ -1718,26 +1761,17 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     NGP_REQUIRE((sigmas == nullptr) == (rgbs == nullptr), "render_uniform: sigmas and rgbs must both be given or both NULL");
     NGP_REQUIRE(T >= 1, "render_uniform: num_steps must be positive");
     hipStream_t s = (hipStream_t)stream;
-    static _Float16* packed = nullptr;  // setup-time scratch, one per process
-    if (!packed && hipMalloc(&packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) != hipSuccess) {
-        set_error("render_uniform: hipMalloc failed");
-        return NGP_ENODEVICE;
-    }
+    // No scratch of the library's own: the fragment-major weights are the caller's, packed once per parameter version
+    // (a process-wide buffer here would be shared by calls that run concurrently on different streams with different models)
+    NGP_REQUIRE(model && model->packed_weights, "render_uniform: model->packed_weights is NULL (ngp_pack_weights fills it)");
     NetArgs na;
     GridLevels lv;
-    int rc = fill_net(model, nullptr, packed, na, lv);
+    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
-    const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
-    k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
-                                                         (const _Float16*)model->color_weights, na.col_mm, packed);
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_uniform<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform<0>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform<1>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform<2>), 96 * 1024);
     uint32_t blocks = div_up(N, 4);
     if (blocks > 1024) blocks = 1024;   // 4 workgroups of 4 waves per CU; each wave strides over rays
     ProfScope prof("render_uniform", s, (double)N * T);
@@ -1758,26 +1792,17 @@ int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* 
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(xyzs && dirs && sigmas && rgbs, "network_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    static _Float16* packed = nullptr;  // setup-time scratch, one per process
-    if (!packed && hipMalloc(&packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) != hipSuccess) {
-        set_error("network_forward: hipMalloc failed");
-        return NGP_ENODEVICE;
-    }
+    // No scratch of the library's own: the fragment-major weights are the caller's, packed once per parameter version
+    // (a process-wide buffer here would be shared by calls that run concurrently on different streams with different models)
+    NGP_REQUIRE(model && model->packed_weights, "network_forward: model->packed_weights is NULL (ngp_pack_weights fills it)");
     NetArgs na;
     GridLevels lv;
-    int rc = fill_net(model, nullptr, packed, na, lv);
+    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
-    const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
-    k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
-                                                         (const _Float16*)model->color_weights, na.col_mm, packed);
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_network_forward<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<0>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<1>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<2>), 96 * 1024);
     const uint32_t n_tiles = div_up(M, 16);
     uint32_t blocks = div_up(n_tiles, 4);
     if (blocks > 1024) blocks = 1024;

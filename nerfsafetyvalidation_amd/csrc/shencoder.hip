@@ -107,10 +107,9 @@ __global__ void __launch_bounds__(kShBlock) k_sh_backward(const float* __restric
     grad_inputs[t] = acc;
 }
 
-static const ShConst& sh_constants() {
-    static ShConst k;
-    static bool init = false;
-    if (!init) {
+static ShConst make_sh_constants() {
+    ShConst k;
+    {
         for (int l = 0; l < 8; l++)
             for (int m = -l; m <= l; m++) {
                 const int am = m < 0 ? -m : m;
@@ -120,8 +119,11 @@ static const ShConst& sh_constants() {
                 if (am) K *= sqrt(2.0) * ((am & 1) ? -1.0 : 1.0);
                 k.K[l * l + l + m] = (float)K;
             }
-        init = true;
     }
+    return k;
+}
+static const ShConst& sh_constants() {
+    static const ShConst k = make_sh_constants();   // (C++11 magic static: initialised once, safely, whichever thread comes first)
     return k;
 }
 

@@ -91,5 +91,15 @@ def render_views_sharded(render_view, n_views, group=None, rank=None, world_size
                 outs.append(out)
     else:
         outs = [render_view(i) for i in range(lo, hi)]
+    if n_views < world_size and world_size > 1:
+        # some ranks have no view (e.g. one frame on 8 GPUs): they still have to enter every all_gather with a zero-row tensor of
+        # the right trailing shape, so rank 0 (which always owns a view) shares the schema first.  Only in this case.
+        schema = [[(k, tuple(v.shape), v.dtype) for k, v in outs[0].items()] if rank == 0 else None]
+        dist.broadcast_object_list(schema, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                                   device=device if dist.get_backend(group) == "nccl" else None)
+        if not outs:
+            dev = device if device is not None else "cpu"
+            empty = {k: torch.empty((0,) + shape, dtype=dtype, device=dev) for k, shape, dtype in schema[0]}
+            return {k: gather_views(v, n_views, group) for k, v in empty.items()}
     keys = outs[0].keys() if outs else []
     return {k: gather_views(torch.stack([o[k] for o in outs], 0), n_views, group) for k in keys}

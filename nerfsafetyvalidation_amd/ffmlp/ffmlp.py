@@ -50,10 +50,14 @@ class _ffmlp_forward(Function):
         grad_weights = torch.zeros_like(weights)
         backward_buffer = torch.zeros(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         lib = _lib.lib()
+        # split-K partials of the weight gradients: this call's own scratch from torch's (stream-aware) caching allocator, so
+        # backward passes running concurrently on other streams never share it
+        wbytes = lib.ngp_ffmlp_backward_workspace(B, input_dim, hidden_dim, num_layers)
+        work = torch.empty((wbytes + 3) // 4, dtype=torch.float32, device=grad.device)
         _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(weights), _lib.ptr(forward_buffer), B,
                                           input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                                           int(calc_grad_inputs), _lib.ptr(backward_buffer), _lib.ptr(grad_inputs),
-                                          _lib.ptr(grad_weights), _lib.stream()), "ffmlp_backward")
+                                          _lib.ptr(grad_weights), _lib.ptr(work), wbytes, _lib.stream()), "ffmlp_backward")
         if calc_grad_inputs:
             return grad_inputs, grad_weights, None, None, None, None, None, None, None, None
         return None, grad_weights, None, None, None, None, None, None, None, None

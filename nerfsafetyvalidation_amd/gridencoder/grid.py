@@ -69,11 +69,14 @@ class _grid_encode(Function):
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if calc_grad_inputs else None
 
         lib = _lib.lib()
+        # scratch of the binned table-gradient scatter (large fp16 batches only): this call's own, from torch's stream-aware allocator
+        wbytes = lib.ngp_grid_encode_backward_workspace(B, D, C, L, _lib.dtype_code(embeddings)) if grad_embeddings is not None else 0
+        work = torch.empty(wbytes, dtype=torch.uint8, device=grad.device) if wbytes else None
         _lib.check(lib.ngp_grid_encode_backward(_lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings), _lib.host_i32(offsets),
                                                 _lib.ptr(grad_embeddings), B, D, C, L, S, H, int(calc_grad_inputs),
                                                 _lib.ptr(dy_dx) if calc_grad_inputs else None, _lib.ptr(grad_inputs), gridtype,
-                                                int(ctx.align_corners), _lib.dtype_code(embeddings), _lib.stream()),
-                   "grid_encode_backward")
+                                                int(ctx.align_corners), _lib.dtype_code(embeddings), _lib.ptr(work), wbytes,
+                                                _lib.stream()), "grid_encode_backward")
         if calc_grad_inputs:
             return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None
         return None, grad_embeddings, None, None, None, None, None, None

@@ -60,6 +60,7 @@ class NeRFRenderer(nn.Module):
         self.min_near = min_near
         self.density_thresh = density_thresh
         self.bg_radius = bg_radius
+        self._fused_cache = None
         self.fused = True  # MI355X extension: allow the fused render entry point in eval-mode run_cuda
         self.return_last_tensors = True  # fused path: also return the last iteration's sigmas / rgbs (renderer.py:383-384)
 
@@ -100,6 +101,24 @@ class NeRFRenderer(nn.Module):
     def fused_model(self):
         """Networks that ngp_render_rays can evaluate return an `_fused.FusedModel`; others return None."""
         return None
+
+    def invalidate_fused(self):
+        """Drop the fused renderer's fp16 snapshot of the parameters (table, weight blobs, per-cell records).  The snapshot is
+        keyed on the parameters' (data_ptr, _version) -- every torch in-place op and this package's Adam bump it -- but writes
+        through `.data` (torch_ema's copy_to / restore in the reference Trainer, nerf/utils.py:846-850,932-933) or raw pointers do
+        not: call this after such a write.  Entering training mode and load_state_dict call it themselves."""
+        from .. import _fused
+        with _fused.CACHE_LOCK:
+            self._fused_cache = None
+
+    def train(self, mode=True):
+        if mode:
+            self.invalidate_fused()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_fused()
+        return super().load_state_dict(*args, **kwargs)
 
     def reset_extra_state(self):
         if not self.cuda_ray:

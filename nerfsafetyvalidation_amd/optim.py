@@ -44,4 +44,7 @@ class Adam(torch.optim.Optimizer):
                 _lib.check(lib.ngp_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(),
                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
                                              float(grad_scale), _lib.stream()), "adam_step")
+                # the kernel wrote through the raw pointer: tell autograd (and every cache keyed on `_version`, e.g. the fused
+                # renderer's fp16 snapshot, _fused.FusedModel.valid_for) that the parameter changed
+                torch.autograd.graph.increment_version(p)
         return loss

@@ -18,9 +18,12 @@ for R in (16, 23, 33, 48, 70, 101, 212, 443, 928, 1943, 4068):
     grad = torch.randn(1, B, 2, device=dev).to(dtype)
     gemb = torch.zeros_like(emb)
     offs = _lib.host_i32(enc.offsets)
+    wbytes = lib.ngp_grid_encode_backward_workspace(B, 3, 2, 1, 1 if dtype == torch.half else 0)
+    work = torch.empty(max(wbytes, 1), dtype=torch.uint8, device=dev)
     def run():
         _lib.check(lib.ngp_grid_encode_backward(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), offs, gemb.data_ptr(), B, 3, 2, 1, 0.0, R, 0, None, None,
-                                                0, 0, 1 if dtype == torch.half else 0, torch.cuda.current_stream().cuda_stream))
+                                                0, 0, 1 if dtype == torch.half else 0, work.data_ptr() if wbytes else None, wbytes,
+                                                torch.cuda.current_stream().cuda_stream))
     run(); torch.cuda.synchronize(); lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
     for _ in range(3): run()
     torch.cuda.synchronize(); lib.ngp_prof_enable(0)

@@ -44,7 +44,15 @@ def test_ctypes_layer_binds_every_symbol():
     assert lib.ngp_version() >= 100
     assert isinstance(lib.ngp_last_error(), bytes)
     assert lib.ngp_march_rays_train_workspace(1000) >= 4000
-    assert ctypes.sizeof(_lib.ModelStruct) == 112 and ctypes.sizeof(_lib.RenderStats) == 40
+    # caller-owned scratch sizes are host arithmetic (no GPU): split-K partials of the FFMLP weight gradients, bins of the grid scatter
+    P = 64 * (32 + 64 + 16)
+    assert lib.ngp_ffmlp_backward_workspace(256 * 1000, 32, 64, 2) == 1000 * P * 4
+    assert lib.ngp_ffmlp_backward_workspace(16, 32, 64, 2) == P * 4
+    assert lib.ngp_grid_encode_backward_workspace(1 << 20, 3, 2, 16, _lib.NGP_F16) > 0
+    assert lib.ngp_grid_encode_backward_workspace(1 << 20, 3, 2, 16, _lib.NGP_F32) == 0
+    assert lib.ngp_grid_encode_backward_workspace(4096, 3, 2, 16, _lib.NGP_F16) == 0
+    assert lib.ngp_packed_weights_bytes() == 2 * ((2048 + 2 * 4096 + 1024) + (2048 + 3 * 4096 + 1024))
+    assert ctypes.sizeof(_lib.ModelStruct) == 120 and ctypes.sizeof(_lib.RenderStats) == 40
 
 
 def test_product_never_imports_the_oracle():

@@ -79,3 +79,23 @@ def test_linear_to_ffmlp_blob_and_back():
         CK.linear_weights_to_ffmlp_blob(ws[:2])
     with pytest.raises(ValueError):
         CK.linear_weights_to_ffmlp_blob([torch.zeros(48, 32), torch.zeros(48, 48), torch.zeros(3, 48)])
+
+
+def test_trainer_checkpoint_with_numpy_scalar_stats_loads(tmp_path):
+    """A reference checkpoint written after an evaluation carries numpy.float64 scalars in stats (PSNRMeter.measure returns
+    V / N with V a numpy scalar, nerf/utils.py:212,923,980).  It is written here the way the reference Trainer writes it
+    (plain torch.save of the dict) and must load through the weights-only reader."""
+    from nerfsafetyvalidation_amd import checkpoint as CK
+    a = _net(1, True)
+    state = {"epoch": 3, "global_step": 99, "mean_count": 1024, "mean_density": 0.25,
+             "stats": {"loss": [0.1, 0.05], "valid_loss": [np.float64(0.07)], "results": [np.float64(27.5), np.float64(29.25)],
+                       "checkpoints": ["ngp_ep0002.pth"], "best_result": np.float64(29.25)},
+             "model": a.state_dict()}
+    path = str(tmp_path / "ngp_ep0003.pth")
+    torch.save(state, path)
+    with pytest.raises(Exception):                 # the plain weights-only loader refuses the numpy scalar global
+        torch.load(path, weights_only=True)
+    b = _net(1, True)
+    missing, unexpected, meta = CK.load_checkpoint(b, path)
+    assert missing == [] and unexpected == []
+    assert meta["stats"]["best_result"] == 29.25 and meta["stats"]["results"] == [27.5, 29.25] and meta["epoch"] == 3

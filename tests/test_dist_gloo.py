@@ -58,7 +58,7 @@ def _worker(rank, world, port, n_views, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_views", [4, 5])
+@pytest.mark.parametrize("n_views", [4, 5, 1])   # 1: rank 1 owns no view and still has to enter the collectives
 def test_sharded_render_all_gather_two_ranks(n_views):
     world = 2
     mgr = mp.Manager()

@@ -418,10 +418,12 @@ def test_ffmlp_backward_buffers_direct(device):
     got = [torch.full((nl, B, hid), 7.0, dtype=torch.float16, device=device), torch.full((B, nin), 7.0, dtype=torch.float16, device=device),
            torch.full((P,), 7.0, dtype=torch.float16, device=device)]
     lib = _lib.lib()
+    wbytes = lib.ngp_ffmlp_backward_workspace(B, nin, hid, nl)
+    work = torch.empty(wbytes // 4, dtype=torch.float32, device=device)
     for calc in (1, 0):
         _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6,
-                                          calc, _lib.ptr(got[0]), _lib.ptr(got[1]) if calc else None, _lib.ptr(got[2]), _lib.stream()),
-                   "ffmlp_backward")
+                                          calc, _lib.ptr(got[0]), _lib.ptr(got[1]) if calc else None, _lib.ptr(got[2]), _lib.ptr(work), wbytes,
+                                          _lib.stream()), "ffmlp_backward")
         torch.cuda.synchronize()
         gb, gi, gw = [t.float().cpu().numpy() for t in got]
         wb, wi, ww = [a.astype(np.float32) for a in want]
@@ -434,11 +436,19 @@ def test_ffmlp_backward_buffers_direct(device):
     # determinism of the split-K reduction: two calls, identical bits
     first = got[2].clone()
     _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6, 0,
-                                      _lib.ptr(got[0]), None, _lib.ptr(got[2]), _lib.stream()), "ffmlp_backward")
+                                      _lib.ptr(got[0]), None, _lib.ptr(got[2]), _lib.ptr(work), wbytes, _lib.stream()), "ffmlp_backward")
     assert torch.equal(first, got[2])
+    # a smaller workspace only changes the batch split (fewer, longer chunks): same sums up to fp32 summation order
+    small = P * 4 * 2
+    _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6, 0,
+                                      _lib.ptr(got[0]), None, _lib.ptr(got[2]), _lib.ptr(work), small, _lib.stream()), "ffmlp_backward")
+    np.testing.assert_allclose(got[2].float().cpu().numpy(), first.float().cpu().numpy(), rtol=4e-3, atol=2e-3 * float(first.abs().max()))
+    with pytest.raises(RuntimeError):       # no workspace: refused (the library keeps no scratch of its own)
+        _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6, 0,
+                                          _lib.ptr(got[0]), None, _lib.ptr(got[2]), None, 0, _lib.stream()), "ffmlp_backward")
     with pytest.raises(RuntimeError):
         _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, 48, nl, 0, 6, 0,
-                                          _lib.ptr(got[0]), None, _lib.ptr(got[2]), _lib.stream()), "ffmlp_backward")
+                                          _lib.ptr(got[0]), None, _lib.ptr(got[2]), _lib.ptr(work), wbytes, _lib.stream()), "ffmlp_backward")
 
 
 def test_ffmlp_rejects_bad_shapes(device):
