@@ -41,6 +41,10 @@ def parse():
                                                            "(nerfsafetyvalidation_amd.pipeline.FramePipeline); 1 = strictly one after the other")
     p.add_argument("--batched-views", type=int, default=4, help="extra, untimed leg: cameras per render call (0 = skip); reported under 'batched'")
     p.add_argument("--no-last", action="store_true", help="do not materialise the last iteration's sigmas/rgbs tensors")
+    p.add_argument("--workload", default="frames", choices=["frames", "rollout"],
+                   help="frames: BASELINE configs[1], the headline metric (default).  rollout: BASELINE configs[4], the Monte-Carlo "
+                        "stress-test rollout (nerfsafetyvalidation_amd/rollout.py); a step = one simulator step of every simulation in flight")
+    p.add_argument("--sims-per-gpu", type=int, default=6, help="rollout: simulations per rank (weak scaling)")
     return p.parse_args()
 
 
@@ -59,8 +63,75 @@ def pmc_traffic_per_launch():
         return None
 
 
+def rollout_main(args):
+    """BASELINE configs[4]: Monte-Carlo rollout, simulations sharded over the ranks (no data-path collective; the CSV rows are
+    gathered once at the end).  A step = one NerfSimulator.step of every simulation of the rank: 2 full-frame renders through
+    NeRFRenderer.run (512 uniform samples per ray, the path validate.py -O takes) + the Gaussian-approximation UQ."""
+    import torch
+    import torch.distributed as dist
+
+    from nerfsafetyvalidation_amd import rollout as RO
+    from nerfsafetyvalidation_amd.scene import StonehengeScene
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    dev_index = min(local_rank, torch.cuda.device_count() - 1) if world > 1 else 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(args.backend, **({"device_id": torch.device("cuda", dev_index)} if args.backend == "nccl" else {}))
+    dev = torch.device("cuda", dev_index)
+    H = W = args.size
+    sc = StonehengeScene(H=H, W=W, bound=2)
+    model = sc.build_model(dev, cuda_ray=False)
+    kw = dict(num_steps=512, upsample_steps=0, max_ray_batch=4096)    # validate.py:72-75 defaults
+    n_sims = args.sims_per_gpu * world
+
+    def run(steps, seed):
+        return RO.run_rollout(model, sc.intrinsics, H, W, n_sims, steps, seed=seed, rank=rank, world_size=world, in_flight=args.in_flight,
+                              render_kwargs=kw, gather=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup, 1000)
+    barrier()
+    t0 = time.perf_counter()
+    rows, counters = run(args.steps, 0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(counters["frames"]), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[1])
+    frames = float(tot[0])
+    if rank == 0:
+        samples = frames * H * W * 512
+        print(json.dumps({
+            "metric": "rendered_samples_per_sec", "value": round(samples / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"Monte-Carlo stress-test rollout (BASELINE configs[4]): {n_sims} simulations x {args.steps} steps, per step 2 "
+                                   f"renders of {H}x{W} through NeRFRenderer.run (512 uniform samples per ray) + Gaussian-approximation UQ",
+                       "simulations": n_sims, "simulations_in_flight_per_gpu": args.in_flight,
+                       "parallelism": f"simulations sharded x{world}, one all_gather of the CSV rows at the end" if world > 1 else "single GPU"},
+            "frames_per_sec": round(frames / elapsed, 3), "simulator_steps_per_sec": round(frames / 2 / elapsed, 3),
+            "rows": int(rows.shape[0]), "mean_sigma_d_opt": float(rows[:, 21].mean()), "collisions": int(rows[:, 22].sum())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == "rollout":
+        return rollout_main(args)
     import numpy as np
     import torch
     import torch.distributed as dist

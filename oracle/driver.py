@@ -90,14 +90,17 @@ class OracleNetwork:
         sigma = np.exp(h[:, 0].astype(np.float32))
         return sigma, h[:, 1:]
 
-    def forward(self, xyzs, dirs):
-        sigma, geo = self.density(xyzs)
+    def color(self, dirs, geo):
+        """network_ff.py:63-70 (the colour half of forward; also what the masked color() evaluates, :104-134)"""
         sh = oracle_sh(dirs).astype(np.float16)  # FFMLP casts its input to half (custom_fwd(cast_inputs=torch.half))
         cin = np.concatenate([sh, geo, np.zeros((geo.shape[0], 1), np.float16)], 1)
         h = oracle_ffmlp(cin, self.cw, 32, 64, self.nlc)[:, :3]
         hf = h.astype(np.float32)
-        rgb = (1.0 / (1.0 + np.exp(-hf))).astype(np.float16)  # torch.sigmoid on a half tensor rounds to half
-        return sigma, rgb
+        return (1.0 / (1.0 + np.exp(-hf))).astype(np.float16)  # torch.sigmoid on a half tensor rounds to half
+
+    def forward(self, xyzs, dirs):
+        sigma, geo = self.density(xyzs)
+        return sigma, self.color(dirs, geo)
 
 
 def oracle_run_cuda(net, rays_o, rays_d, bitfield, bound, cascade, density_scale, min_near=0.2, dt_gamma=0.0, max_steps=1024,
@@ -233,3 +236,86 @@ def oracle_uq_objective(c, d, r, params):
     mu_d, sigma_d = params
     den = np.sum(c ** 2 * sigma_d ** 2 * d ** 2)
     return float(np.log(np.sum(c ** 2 * d ** 2 * sigma_d ** 2)) + (np.mean(np.asarray(r, np.float64)) - np.sum(c * mu_d * d)) ** 2 / den)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Monte-Carlo rollout (BASELINE configs[4]): numpy restatement of the reference lines the product's rollout.py follows
+# ---------------------------------------------------------------------------------------------------------------------
+def _rot_x32(phi):
+    """nav/math_utils.py:12-15 with torch's float32 cos / sin of the float32 angle"""
+    p = np.float32(phi)
+    c, s = np.cos(p, dtype=np.float32), np.sin(p, dtype=np.float32)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], np.float32)
+
+
+def _skew32(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], np.float32)
+
+
+def oracle_vec_to_rot(v):
+    """nav/math_utils.py:151-165"""
+    v = np.asarray(v, np.float32)
+    angle = np.sqrt(np.sum(v * v, dtype=np.float32), dtype=np.float32)
+    S = _skew32(v / (np.float32(1e-10) + angle))
+    return (np.eye(3, dtype=np.float32) + np.sin(angle, dtype=np.float32) * S + (np.float32(1) - np.cos(angle, dtype=np.float32)) * (S @ S)).astype(np.float32)
+
+
+def oracle_rot_to_vec(R, eps=1e-7):
+    """nav/math_utils.py:104-149"""
+    R = np.asarray(R, np.float32)
+    x = (np.trace(R).astype(np.float32) - np.float32(1)) / np.float32(2)
+    if abs(x) <= 1 - eps:
+        angle = np.arccos(x, dtype=np.float32)
+    else:
+        slope = np.arccos(1 - eps) / eps
+        sg = np.sign(x)
+        angle = np.float32(np.arccos(np.float32(sg * (1 - eps)), dtype=np.float32) - np.float32(slope) * sg * np.float32(abs(x) - 1 + eps))
+    vec = np.float32(1) / (np.float32(2) * np.sin(angle + np.float32(1e-10), dtype=np.float32)) * np.array(
+        [R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]], np.float32)
+    if angle == 0:
+        vec = np.zeros(3, np.float32)
+    return (angle * vec).astype(np.float32)
+
+
+def oracle_drone_dynamics(state, action, dt, mass=1.0, g=10.0, inertia=None):
+    """nav/agent_helpers.py:102-148, float32"""
+    inertia = np.eye(3, dtype=np.float32) if inertia is None else np.asarray(inertia, np.float32)
+    inv = np.linalg.inv(inertia).astype(np.float32)
+    state, action = np.asarray(state, np.float32), np.asarray(action, np.float32)
+    pos, v, omega = state[0:3], state[3:6], state[9:12]
+    R = oracle_vec_to_rot(state[6:9])
+    dv = (np.array([0, 0, -mass * g], np.float32) + R @ np.array([0, 0, action[0]], np.float32)) / np.float32(mass)
+    domega = inv @ (action[1:] - np.cross(omega, inertia @ omega).astype(np.float32))
+    angle = (omega * np.float32(dt)).astype(np.float32)
+    theta = np.sqrt(np.sum(angle * angle, dtype=np.float32), dtype=np.float32)
+    exp_i = np.eye(3, dtype=np.float32)
+    if theta != 0:
+        K = _skew32(angle / theta)
+        exp_i = (exp_i + np.sin(theta, dtype=np.float32) * K + (np.float32(1) - np.cos(theta, dtype=np.float32)) * (K @ K)).astype(np.float32)
+    nxt = np.zeros(12, np.float32)
+    nxt[0:3] = pos + v * np.float32(dt)
+    nxt[3:6] = v + dv.astype(np.float32) * np.float32(dt)
+    nxt[6:9] = oracle_rot_to_vec((R @ exp_i).astype(np.float32))
+    nxt[9:12] = omega + domega.astype(np.float32) * np.float32(dt)
+    return nxt
+
+
+def oracle_camera_pose(state):
+    """agent_helpers.py:58-61,75 (body-frame pose) -> estimator_helpers.py:227-237 (camera) -> math_utils.py:19-31 (ngp axes)"""
+    R = oracle_vec_to_rot(np.asarray(state, np.float32)[6:9])
+    body = _rot_x32(-np.pi / 2) @ (_rot_x32(np.pi / 2) @ R)
+    rot = _rot_x32(np.pi / 2) @ body
+    flip = np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]], np.float32)
+    neg = np.array([[1, 0, 0], [0, -1, 0], [0, 0, -1]], np.float32)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = flip @ rot @ neg
+    pose[:3, 3] = flip @ np.asarray(state, np.float32)[0:3]
+    return pose
+
+
+def oracle_uq_optimize(c, d, r):
+    """gaussian_approximation_density_uncertainty.py:24-51 with the objective evaluated as written, in float64"""
+    from scipy.optimize import minimize
+    st = oracle_uq_statistics(c, d, r)
+    res = minimize(lambda p: oracle_uq_objective(c, d, r, p), [st["mean_d"], st["std_d"]])
+    return float(res.x[0]), float(res.x[1]), st
