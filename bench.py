@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--workload", default="frames", choices=["frames", "rollout"],
                    help="frames: BASELINE configs[1], the headline metric (default).  rollout: BASELINE configs[4], the Monte-Carlo "
                         "stress-test rollout (nerfsafetyvalidation_amd/rollout.py); a step = one simulator step of every simulation in flight")
+    p.add_argument("--single-rank-pg", action="store_true",
+                   help="N = 1 only: create a one-rank process group of --backend and run the per-step tile all_gather anyway (smoke test of "
+                        "the RCCL path and its stream / event ordering on a one-GPU box; off by default: a single GPU has nothing to exchange)")
     p.add_argument("--sims-per-gpu", type=int, default=6, help="rollout: simulations per rank (weak scaling)")
     return p.parse_args()
 
@@ -148,7 +151,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     dev_index = min(local_rank, torch.cuda.device_count() - 1) if world > 1 else 0   # (a gloo rehearsal may share one GPU)
-    if world > 1:
+    collective = world > 1 or args.single_rank_pg
+    if args.single_rank_pg and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
@@ -181,7 +188,7 @@ def main():
         # frame_width: scheduling hint of this build (ngp_render_ctx_set_frame_width); the rendered values do not depend on it
         out = model.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False, frame_width=W)
         st = model.last_render_stats
-        tile = torch.cat([out["image"], out["depth"].unsqueeze(-1)], -1) if world > 1 else None
+        tile = torch.cat([out["image"], out["depth"].unsqueeze(-1)], -1) if collective else None
         return tile, (st["samples_marched"], st["iterations"], st["samples_slots"])
 
     def exchange(tile):
@@ -189,7 +196,7 @@ def main():
         # backend's stream while the next views render; the previous step's gather is completed first.
         if pending:
             pending.pop().finish()
-        pending.append(gather_views_start(tile, world))
+        pending.append(gather_views_start(tile, world, force=args.single_rank_pg))
 
     def render_steps(first, count, pipe):
         """`count` frames starting at step `first`: `in_flight` of them at a time, collectives issued by this thread in step order"""
@@ -218,7 +225,7 @@ def main():
     def barrier():
         while pending:
             pending.pop().finish()        # every exchange started inside the timed region completes inside it
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -281,7 +288,7 @@ def main():
                    "note": "same renderer, rays of several 800x800 cameras in one render call (rays [B, H*W, 3]); not part of `value`"}
 
     tot = torch.tensor([float(samples), float(iters), elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if collective:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -289,7 +296,7 @@ def main():
     total_samples = float(tot[0])
 
     # ---- cpu baseline leg: the oracle on a bounded sample of view 0 (rank 0, N = 1 only)
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import driver as D
         from oracle import oracle as O
@@ -305,6 +312,32 @@ def main():
         cpu = {"value": round(res["samples_marched"] / cpu_t, 1), "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
                "sample": f"rays[::{args.cpu_stride}] of view {view_of(0)} ({ro.shape[0]} of {H * W} rays, {res['samples_marched']} samples, "
                          f"{cpu_t:.1f} s): oracle/ngp_oracle.c (OpenMP) driven by the reference's run_cuda loop"}
+        # ---- parity of the timed path against those same oracle rays (the oracle here is the checker, not the thing measured)
+        hbuf = torch.zeros(H * W, dtype=torch.int32, device=dev)
+        lib.ngp_debug_set_sample_hash(hbuf.data_ptr())
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                v0 = view_of(0)
+                rays0 = get_rays(poses[v0:v0 + 1], intr, H, W)
+                out0 = model.render(rays0["rays_o"], rays0["rays_d"], staged=True, bg_color=1, perturb=False, frame_width=W)
+            torch.cuda.synchronize()
+        finally:
+            lib.ngp_debug_set_sample_hash(None)
+        got_img = out0["image"].float().cpu().numpy()[0][::args.cpu_stride]
+        want_img = res["image"] + (1.0 - res["weights_sum"])[:, None]
+        err = np.abs(got_img - want_img)
+        mse = float(np.mean((got_img - want_img) ** 2))
+        same = hbuf.cpu().numpy().view(np.uint32)[::args.cpu_stride] == res["sample_hash"]
+        hit = res["nears"] < res["fars"]
+        got_dep = out0["depth"].float().cpu().numpy()[0][::args.cpu_stride][hit]
+        want_dep = (np.clip(res["depth"] - res["nears"], 0, None) / (res["fars"] - res["nears"]))[hit]
+        parity = {"against": "CPU oracle (oracle/ngp_oracle.c + the reference's run_cuda loop) on the cpu_baseline rays", "rays": int(ro.shape[0]),
+                  "max_abs_drgb": float(err.max()), "mean_abs_drgb": float(err.mean()), "psnr_db": round(-10 * np.log10(max(mse, 1e-20)), 2),
+                  "max_abs_ddepth": float(np.abs(got_dep - want_dep).max()),
+                  "rays_with_identical_sample_sequence": float(same.mean()),
+                  "reference_iterations": {"gpu": int(model.last_render_stats["iterations"]), "oracle_on_the_sample": int(res["iterations"])},
+                  "note": "fp16 network: MFMA fp32 accumulation vs the oracle's exact-sum model and fp32 vs c10::Half corner accumulation in the "
+                          "fused gather (DESIGN.md section 5); sample sequences (dt, delta bit patterns per ray) are compared through per-ray hashes"}
 
     if rank == 0:
         frames = args.steps * world
@@ -327,17 +360,19 @@ def main():
                        "frames_in_flight": args.in_flight,
                        "frames_in_flight_note": "every frame is rendered by its own NeRFRenderer.render call (800x800 rays); up to this many calls "
                                                 "run concurrently on separate host threads / HIP streams (pipeline.FramePipeline)",
-                       "parallelism": f"camera-sharded x{world}, RCCL all_gather of rendered tiles" if world > 1 else "single GPU"},
+                       "parallelism": f"camera-sharded x{world}, RCCL all_gather of rendered tiles" if world > 1 else
+                                      ("single GPU, one-rank process group with the tile all_gather issued (smoke test)" if collective else "single GPU")},
             "frames_per_sec": round(frames / elapsed, 3),
             "rays_per_sec": round(frames * H * W / elapsed, 1),
             "samples_per_frame": round(total_samples / frames, 1),
             "loop_iterations_per_frame": round(float(tot[1]) / frames, 1),
             "roofline": roof,
             "cpu_baseline": cpu,
+            "parity": parity,
             "batched": batched,
         }
         print(json.dumps(line))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

@@ -40,11 +40,12 @@ class _Gather:
         return torch.cat(pieces, 0)
 
 
-def gather_views_start(local, n_total, group=None):
+def gather_views_start(local, n_total, group=None, force=False):
     """Start the all_gather of per-rank stacks of rendered views and return at once: the collective runs on the backend's own
     stream (RCCL over xGMI) while the caller renders the next views; `.finish()` makes the current stream wait for it.
-    local: [n_local, ...] (n_local may differ by one between ranks)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    local: [n_local, ...] (n_local may differ by one between ranks).  `force`: issue the collective in a one-rank group as well
+    (a smoke test of the backend on a one-GPU box; without it a single rank returns its own stack)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return _Gather(local, None, local.shape[0], local.shape[0], 1, local.device)
     world = dist.get_world_size(group)
     n_max = (n_total + world - 1) // world
@@ -60,14 +61,14 @@ def gather_views_start(local, n_total, group=None):
     return _Gather(out, work, n_total, n_max, world, device)
 
 
-def gather_views(local, n_total, group=None):
+def gather_views(local, n_total, group=None, force=False):
     """all_gather of per-rank stacks of rendered views.  Returns [n_total, ...] on every rank, in global view order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return local
-    return gather_views_start(local, n_total, group).finish()
+    return gather_views_start(local, n_total, group, force).finish()
 
 
-def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None, in_flight=1, device=None):
+def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None, in_flight=1, device=None, force_collective=False):
     """render_view(i) -> dict of tensors for global view i (e.g. {'image': [H*W,3], 'depth': [H*W]}).
     Each rank renders its contiguous block of views; one all_gather per key returns all views everywhere.
     in_flight > 1 (GPU only, `device` required): that many views of this rank are rendered concurrently, each by its own
@@ -102,4 +103,4 @@ def render_views_sharded(render_view, n_views, group=None, rank=None, world_size
             empty = {k: torch.empty((0,) + shape, dtype=dtype, device=dev) for k, shape, dtype in schema[0]}
             return {k: gather_views(v, n_views, group) for k, v in empty.items()}
     keys = outs[0].keys() if outs else []
-    return {k: gather_views(torch.stack([o[k] for o in outs], 0), n_views, group) for k in keys}
+    return {k: gather_views(torch.stack([o[k] for o in outs], 0), n_views, group, force_collective) for k in keys}

@@ -20,12 +20,18 @@ p.add_argument("--size", type=int, default=800)
 p.add_argument("--views", type=int, default=200)
 p.add_argument("--in-flight", type=int, default=3)
 p.add_argument("--backend", default="nccl")
+p.add_argument("--single-rank-pg", action="store_true", help="one process, but WITH a process group of one rank and the collectives issued "
+                                                             "(smoke test of the production backend, RCCL, on a one-GPU box)")
 args = p.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
 dev_index = min(local, torch.cuda.device_count() - 1) if world > 1 else 0
 torch.cuda.set_device(dev_index)
 dev = torch.device("cuda", dev_index)
-if world > 1:
+if args.single_rank_pg and world == 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.update(RANK="0", WORLD_SIZE="1")
+if world > 1 or args.single_rank_pg:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.backend == "nccl":
         dist.init_process_group("nccl", device_id=dev)
@@ -49,7 +55,7 @@ torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
 t0 = time.perf_counter()
-res = render_views_sharded(render_view, args.views, in_flight=args.in_flight, device=dev)
+res = render_views_sharded(render_view, args.views, in_flight=args.in_flight, device=dev, force_collective=args.single_rank_pg)
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
@@ -58,7 +64,8 @@ if rank == 0:
     img = res["image"]
     if os.environ.get("SWEEP_PER_VIEW"):
         print("per-view", img.contiguous().view(torch.int16).to(torch.int64).sum(dim=(1, 2)).tolist())
-    print(json.dumps({"views": args.views, "frame": f"{H}x{W}", "n_gpus": world, "seconds": round(dt, 3), "frames_per_s": round(args.views / dt, 1),
+    print(json.dumps({"views": args.views, "frame": f"{H}x{W}", "n_gpus": world, "backend": dist.get_backend() if dist.is_initialized() else None,
+                      "seconds": round(dt, 3), "frames_per_s": round(args.views / dt, 1),
                       "gathered": list(img.shape), "checksum": int(img.contiguous().view(torch.int16).to(torch.int64).sum())}))   # exact: sum of the fp16 bit patterns
-if world > 1:
+if dist.is_initialized():
     dist.destroy_process_group()

@@ -48,3 +48,34 @@ def test_random_call_sequences_on_shared_contexts(device):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_render_calls.py"), "5", "60"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "bad calls: 0" in out.stdout
+
+
+def test_full_200_view_sweep_through_a_one_rank_rccl_group(device):
+    """BASELINE configs[2] at full size -- all 200 views of the validation sweep at 800x800 -- on this box's one GPU, once without a
+    process group and once through a ONE-RANK `nccl` (= RCCL) group with the tile all_gathers really issued: RCCL is loaded and
+    initialised, all_gather_into_tensor runs on its stream behind the renders of the worker threads (wait_event / record_stream
+    ordering of dist.render_views_sharded), and the gathered images must be the same bits."""
+    args = ["--views", "200", "--size", "800"]
+    plain, s1 = _run([sys.executable, SCRIPT] + args)
+    env_port = str(_free_port())
+    os.environ["MASTER_PORT"] = env_port
+    try:
+        rccl, s2 = _run([sys.executable, SCRIPT, "--single-rank-pg", "--backend", "nccl"] + args)
+    finally:
+        os.environ.pop("MASTER_PORT", None)
+    assert s1["backend"] is None and s2["backend"] == "nccl"
+    assert s1["gathered"] == s2["gathered"] == [200, 640000, 3]
+    assert plain == rccl and s1["checksum"] == s2["checksum"]
+    print(f"200-view sweep: {s1['seconds']} s plain, {s2['seconds']} s through the one-rank RCCL group")
+
+
+def test_bench_exchange_path_through_a_one_rank_rccl_group(device):
+    """bench.py's per-step exchange (async all_gather of the rgb+depth tile on RCCL's stream while the next frames render; worker
+    threads render, the main thread issues the collectives after wait_event / record_stream) with the production backend."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-rank-pg", "--steps", "6", "--warmup", "2", "--profile-steps", "0",
+           "--batched-views", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e9 and "one-rank process group" in line["config"]["parallelism"]
