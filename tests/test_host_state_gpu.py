@@ -178,4 +178,6 @@ def test_two_backward_passes_concurrently(device):
         torch.cuda.synchronize()
         for (w_s, e_s), (w_g, e_g) in zip(serial, got):
             assert torch.equal(w_s, w_g)                                  # split-K in a fixed order: bit-identical
-            np.testing.assert_allclose(e_g.float().cpu().numpy(), e_s.float().cpu().numpy(), rtol=2e-2, atol=2e-3 * float(e_s.abs().max()))
+            # fp16 table gradient: hundreds of fp16 atomic adds per coarse entry, in an order that differs from run to run (as the
+            # reference's, gridencoder.cu:303-311): each add rounds at 2^-11 of the running sum
+            np.testing.assert_allclose(e_g.float().cpu().numpy(), e_s.float().cpu().numpy(), rtol=2e-2, atol=1e-2 * float(e_s.abs().max()))

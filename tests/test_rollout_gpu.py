@@ -69,10 +69,20 @@ def test_rollout_against_the_oracle_loop(device):
             for key in ("A", "B", "R", "mean_d", "std_d"):
                 np.testing.assert_allclose(o["stats"][key], ws[key], rtol=2e-2, atol=1e-6, err_msg=f"{key} sim {sim} step {k}")
             # the optimiser: the product minimises the closed form on its one-pass statistics; the reference's objective as
-            # written (float64), minimised the same way on the product's OWN samples, has to land on the same point
+            # written (float64), minimised the same way on the product's OWN samples.  The objective has no minimum in sigma_d
+            # (log(s^2 A) -> -inf as s -> 0 once mu = R / B): both runs end where BFGS's gradient tolerance stops them, close to
+            # each other but not at a common point -- mu is well determined, sigma and the objective value only roughly
             mu_w, sigma_w, _ = Hh.oracle_uq_optimize(o["rgbs"], o["sigmas"].reshape(-1), o["image"])
             obj = lambda p: Hh.oracle_uq_objective(o["rgbs"], o["sigmas"].reshape(-1), o["image"], p)   # noqa: E731
-            assert abs(obj([o["mu"], o["sigma"]]) - obj([mu_w, sigma_w])) < 1e-3 * max(1.0, abs(obj([mu_w, sigma_w])))
+            np.testing.assert_allclose(o["mu"], mu_w, rtol=1e-2)
+            assert abs(o["sigma"]) < 1e-2 * o["stats"]["std_d"] and abs(sigma_w) < 1e-2 * o["stats"]["std_d"]   # both far down the log(s^2) slope
+            assert abs(obj([o["mu"], o["sigma"]]) - obj([mu_w, sigma_w])) < 0.05 * max(1.0, abs(obj([mu_w, sigma_w])))
+            # ... while the objective itself, at fixed parameters, is the same function on both sides
+            from nerfsafetyvalidation_amd.uncertainty.quantification.gaussian_approximation_density_uncertainty import GaussianApproximationDensityUncertainty as UQ
+            for prm in ([0.5, 1.0], [mu_w, 2 * abs(sigma_w)], [0.02, 0.3]):
+                uq = UQ.__new__(UQ)
+                uq.stats = o["stats"]
+                np.testing.assert_allclose(uq.objective(prm), obj(prm), rtol=1e-5, atol=1e-5)
             worst_sigma = max(worst_sigma, abs(o["sigma"] - sigma_w))
             # ---- the row (MonteCarlo.py:58-116), with the product's sigma feeding the next step on both sides
             loglik = RO.trajectory_log_likelihood(noise, mean, std)
