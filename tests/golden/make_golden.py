@@ -88,7 +88,30 @@ def _make_raymarching_shim():
         return tuple()
 
     def sph_from_ray(rays_o, rays_d, radius):
-        raise NotImplementedError
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3).float(), rays_d.contiguous().view(-1, 3).float()
+        coords = torch.empty(rays_o.shape[0], 2)
+        O.sph_from_ray(rays_o, rays_d, float(radius), rays_o.shape[0], coords)
+        return coords
+
+    def morton3D(coords):
+        coords = coords.int().contiguous()
+        out = torch.empty(coords.shape[0], dtype=torch.int32)
+        O.morton3D(coords, coords.shape[0], out)
+        return out
+
+    def morton3D_invert(indices):
+        indices = indices.int().contiguous()
+        out = torch.empty(indices.shape[0], 3, dtype=torch.int32)
+        O.morton3D_invert(indices, indices.shape[0], out)
+        return out
+
+    def packbits(grid, thresh, bitfield=None):
+        grid = grid.contiguous().float()
+        C_, H3 = grid.shape
+        if bitfield is None:
+            bitfield = torch.empty(C_ * H3 // 8, dtype=torch.uint8)
+        O.packbits(grid, C_ * H3 // 8, float(thresh), bitfield)
+        return bitfield
 
     def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
                          align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
@@ -131,12 +154,92 @@ def _make_raymarching_shim():
                                             image, M, N, grad_sigmas, grad_rgbs)
             return grad_sigmas, grad_rgbs, None, None
 
+    m.morton3D, m.morton3D_invert, m.packbits = morton3D, morton3D_invert, packbits
     m.near_far_from_aabb, m.march_rays, m.composite_rays, m.sph_from_ray = near_far_from_aabb, march_rays, composite_rays, sph_from_ray
     m.march_rays_train, m.composite_rays_train = march_rays_train, _CompositeTrain.apply
     return m
 
 
 sys.modules["raymarching"] = _make_raymarching_shim()
+
+
+def _h(t):
+    """torch CPU tensor (any float dtype) -> contiguous float16 numpy array"""
+    return np.ascontiguousarray(t.detach().cpu().float().numpy().astype(np.float16))
+
+
+def _make_ffmlp_shim():
+    """`_ffmlp` over the oracle (ffmlp/src/ffmlp.h:8-15).  On CUDA the wrapper's custom_fwd(cast_inputs=torch.half) hands the native
+    module half tensors; on this CPU-only host that cast does not happen (it only applies to CUDA tensors), so the shim performs
+    it: operands are rounded to fp16 here, results are written back into the wrapper's (fp32) buffers as the fp16 values."""
+    m = types.ModuleType("_ffmlp")
+
+    def fwd(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, buffer, outputs, keep):
+        out = np.empty((B, output_dim), np.float16)
+        fb = np.empty((num_layers, B, hidden_dim), np.float16) if keep else None
+        O.ffmlp_forward(_h(inputs), _h(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, fb, out)
+        outputs.copy_(torch.from_numpy(out.astype(np.float32)).to(outputs.dtype))
+        if keep:
+            buffer.copy_(torch.from_numpy(fb.astype(np.float32)).to(buffer.dtype))
+
+    m.ffmlp_forward = lambda i, w, B, a, b, c, d, e, f, buf, out: fwd(i, w, B, a, b, c, d, e, f, buf, out, True)
+    m.ffmlp_inference = lambda i, w, B, a, b, c, d, e, f, buf, out: fwd(i, w, B, a, b, c, d, e, f, buf, out, False)
+
+    def bwd(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_gi,
+            backward_buffer, grad_inputs, grad_weights):
+        bb = np.zeros((num_layers, B, hidden_dim), np.float16)
+        gi = np.zeros((B, input_dim), np.float16)
+        gw = np.zeros(weights.numel(), np.float16)
+        O.ffmlp_backward(_h(grad), _h(inputs), _h(weights), _h(forward_buffer), B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                         output_activation, bool(calc_gi), bb, gi, gw)
+        grad_weights.copy_(torch.from_numpy(gw.astype(np.float32)).to(grad_weights.dtype))
+        if calc_gi:
+            grad_inputs.copy_(torch.from_numpy(gi.astype(np.float32)).to(grad_inputs.dtype))
+
+    m.ffmlp_backward = bwd
+    m.allocate_splitk = lambda n: None
+    m.free_splitk = lambda: None
+    return m
+
+
+sys.modules["_ffmlp"] = _make_ffmlp_shim()
+if "turtle" not in sys.modules:            # ffmlp/ffmlp.py:2 imports two names from the stdlib `turtle` (Tk) module and never uses them
+    try:
+        import turtle  # noqa: F401
+    except Exception:
+        sys.modules["turtle"] = MagicMock()
+
+
+class _autocast_on:
+    """Gives the reference wrappers, on this CPU-only host, the autocast behaviour they have on the GPU under `with autocast()`
+    (torch.autocast('cuda') cannot be enabled without a CUDA device).  Two switches of TORCH are overridden, nothing of the
+    reference: torch.is_autocast_enabled reports True (gridencoder/grid.py:36-39 then casts the table to half), and custom_fwd's
+    input cast -- which only touches tensors living on the autocast device -- accepts CPU tensors, so that
+    custom_fwd(cast_inputs=torch.half) of ffmlp/ffmlp.py:18 and custom_fwd(cast_inputs=torch.float32) of activation.py:6,
+    shencoder/sphere_harmonics.py:16 and the raymarching wrappers cast exactly as they do for CUDA tensors."""
+
+    def __enter__(self):
+        import torch.amp.autocast_mode as am
+        self._am, self._keep, self._keep_cast = am, torch.is_autocast_enabled, am._cast
+        torch.is_autocast_enabled = lambda *a, **k: True
+        orig = am._cast
+
+        def cast(value, device_type, dtype):
+            if isinstance(value, torch.Tensor):
+                return value.to(dtype) if (value.is_floating_point() and value.dtype is not torch.float64) else value
+            if isinstance(value, (list, tuple)):
+                return type(value)(cast(v, device_type, dtype) for v in value)
+            if isinstance(value, dict):
+                return {k: cast(v, device_type, dtype) for k, v in value.items()}
+            return orig(value, device_type, dtype)
+
+        am._cast = cast
+
+    def __exit__(self, *exc):
+        torch.is_autocast_enabled = self._keep
+        self._am._cast = self._keep_cast
+        return False
+
 
 # ---- 3. the reference's host code ---------------------------------------------------------------------------
 sys.path.insert(0, REF)
@@ -384,15 +487,157 @@ def gen_rollout():
          sigma_coeffs=np.array([0.02, 0.4, 0.3]))
 
 
+def _small_grid(net, H):
+    """the renderer hard-codes a 128^3 grid (renderer.py:74); a smaller one keeps the fixtures small.  Every line of the
+    maintenance code reads self.grid_size and the buffers' shapes, so swapping both is all it takes."""
+    net.grid_size = H
+    net.density_grid = torch.zeros(net.cascade, H ** 3)
+    net.density_bitfield = torch.zeros(net.cascade * H ** 3 // 8, dtype=torch.uint8)
+    return net
+
+
+def gen_density_grid():
+    """NeRFRenderer.mark_untrained_grid (renderer.py:388-449) and update_extra_state (:453-544: full sweep, then the partial update
+    of iteration >= 16) executed by the reference on a 32^3 x 2 grid with the nn.Linear network on the oracle encoders.  The random
+    draws come from torch's CPU generator under the stored seeds (rand_like / randint in the order the reference makes them), so a
+    test can replay them."""
+    H, bound = 32, 2
+    net = _small_grid(_ref_network(bound, True, 1.0), H)
+    # ---- mark_untrained_grid: 7 cameras of the orbit looking at the centre, S = 16 (several blocks per axis, cameras in two batches of <= 16 ... and 4)
+    poses = SC.orbit_poses(radius=1.2)[[0, 33, 71, 104, 138, 171, 199]]
+    intr = SC.intrinsics(64, 64)
+    net.mark_untrained_grid(poses, intr, S=16)
+    marked = net.density_grid.clone().numpy()
+    net.mark_untrained_grid(poses[:2], intr, S=64)                 # fewer cameras, one block: a different marking (on top of the first)
+    marked2 = net.density_grid.clone().numpy()
+    # ---- update_extra_state: a full sweep, a second full sweep (EMA with decay), then a partial update
+    net.density_grid.zero_()
+    net.density_grid[marked == -1] = -1                              # keep the first marking: untrained cells stay -1 through the updates
+    net.density_thresh = 0.01
+    res = {}
+    net.step_counter[:3, 0] = torch.tensor([4096, 8192, 1000], dtype=torch.int32)
+    net.local_step = 3
+    for tag, seed, it in (("full1", 101, 0), ("full2", 102, 1), ("partial", 103, 16)):
+        net.iter_density = it
+        torch.manual_seed(seed)
+        net.update_extra_state(decay=0.95, S=128)
+        res[f"{tag}_grid"] = net.density_grid.clone().numpy()
+        res[f"{tag}_bitfield"] = net.density_bitfield.clone().numpy()
+        res[f"{tag}_mean"] = np.float64(net.mean_density)
+        res[f"{tag}_seed"] = seed
+        res[f"{tag}_mean_count"] = net.mean_count
+    save("density_grid.npz", grid_size=H, bound=bound, density_scale=1.0, table_seed=0, poses=poses, intrinsics=intr, marked=marked, marked2=marked2,
+         **res, **_weights(net))
+
+
+def gen_background():
+    """bg_radius > 0 (renderer.py:228-236,277-282; network.py:145-161; raymarching.cu:164-211): the environment-map branch of run and
+    run_cuda -- sph_from_ray -> 2-D hash grid + SH -> bg MLP -> sigmoid -> mixed under the remaining transmittance."""
+    bound, H, W = 1, 10, 10
+    torch.manual_seed(6)
+    net = RefNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, density_scale=12.0, min_near=0.2, density_thresh=0.01, bg_radius=3)
+    g = torch.Generator().manual_seed(0)
+    net.encoder.embeddings.data.copy_((torch.rand(net.encoder.embeddings.shape, generator=g) - 0.5).half().float())
+    net.encoder_bg.embeddings.data.copy_((torch.rand(net.encoder_bg.embeddings.shape, generator=g) - 0.5).half().float())
+    net = net.eval()
+    sc = SC.StonehengeScene(H=H, W=W, bound=bound, radius=1.6)
+    net.density_bitfield = torch.from_numpy(sc.bitfield())
+    rays = ref_get_rays(torch.from_numpy(sc.poses[21:22]), SC.intrinsics(H, W), H, W)
+    with torch.no_grad():
+        sph = sys.modules["raymarching"].sph_from_ray(rays["rays_o"], rays["rays_d"], 3)
+        bg = net.background(sph, rays["rays_d"].reshape(-1, 3))
+        out_c = net.render(rays["rays_o"], rays["rays_d"], staged=True, perturb=False, dt_gamma=0, max_steps=1024)
+        net.cuda_ray = False
+        out_u = net.render(rays["rays_o"], rays["rays_d"], staged=True, perturb=False, num_steps=48, upsample_steps=0)
+    bgw = {f"bg{i}": l.weight.detach().numpy() for i, l in enumerate(net.bg_net)}
+    save("background.npz", bound=bound, H=H, W=W, view=21, radius=1.6, bg_radius=3, density_scale=12.0, sph=sph.numpy(), bg=bg.numpy(),
+         image_cuda=out_c["image"].numpy(), depth_cuda=out_c["depth"].numpy(), image_run=out_u["image"].numpy(), depth_run=out_u["depth"].numpy(),
+         bitfield_sha256=SC.bitfield_sha256(sc.bitfield()), **_weights(net), **bgw)
+
+
+def gen_sh_literal():
+    """Values of the reference's hard-coded spherical-harmonics polynomials (shencoder/src/shencoder.cu:51-355: one C assignment
+    per output and per partial derivative, degree <= 8).  The CUDA kernel cannot run here, but its arithmetic is these literal
+    lines: they are read from the source AS TEXT at generation time, each right-hand side is evaluated in float32 with C's
+    precedence on seeded unit vectors (numeric literals -> float32, pow(z, 3) -> float32 power), and only inputs and values are
+    stored.  Pins the oracle's and the HIP kernel's recurrence-based SH against the reference's own constants and signs."""
+    import re
+    src = open(os.path.join(REF, "shencoder", "src", "shencoder.cu")).read()
+    g = torch.Generator().manual_seed(31)
+    d = torch.randn(257, 3, generator=g)
+    d = (d / d.norm(dim=-1, keepdim=True)).numpy().astype(np.float32)
+    d[0], d[1], d[2] = (0, 0, 1), (1, 0, 0), (0, -1, 0)
+    f32 = np.float32
+    x, y, z = d[:, 0].copy(), d[:, 1].copy(), d[:, 2].copy()
+    env = {"x": x, "y": y, "z": z, "pow": lambda a, b: np.power(a, f32(b), dtype=np.float32), "f32": f32}
+    # shencoder.cu:45-47, the shared products
+    for line in re.findall(r"scalar_t ((?:\w+=[^;,]+,?\s*)+);", src):
+        for name, expr in re.findall(r"(\w+)=([^,;]+)", line):
+            env[name] = eval(expr, {}, env).astype(np.float32)
+    assert {"xy", "x2", "z6", "xyz"} <= set(env)
+    lit = re.compile(r"(?<![\w.])(\d+\.\d*(?:[eE][-+]?\d+)?)f?")
+    out = {"outputs": np.zeros((d.shape[0], 64), np.float32), "dx": np.zeros((d.shape[0], 64), np.float32),
+           "dy": np.zeros((d.shape[0], 64), np.float32), "dz": np.zeros((d.shape[0], 64), np.float32)}
+    seen = {k: set() for k in out}
+    for name, idx, expr in re.findall(r"^\s*(outputs|dx|dy|dz)\[(\d+)\] = (.*?) ;", src, flags=re.M):
+        val = eval(lit.sub(lambda m: f"f32({m.group(1)})", expr), {}, env)
+        out[name][:, int(idx)] = np.broadcast_to(np.asarray(val, np.float32), x.shape)
+        seen[name].add(int(idx))
+    assert all(seen[k] == set(range(64)) for k in out), {k: len(v) for k, v in seen.items()}
+    save("sh_literal.npz", d=d, Y=out["outputs"], dY=np.stack([out["dx"], out["dy"], out["dz"]], 1))
+
+
+def _ref_network_ff(bound, cuda_ray, density_scale):
+    from nerf.network_ff import NeRFNetwork as RefFF
+    net = RefFF(encoding="hashgrid", bound=bound, cuda_ray=cuda_ray, density_scale=density_scale, min_near=0.2, density_thresh=0.01, bg_radius=-1)
+    g = torch.Generator().manual_seed(0)
+    net.encoder.embeddings.data.copy_((torch.rand(net.encoder.embeddings.shape, generator=g) - 0.5).half().float())
+    return net.eval()
+
+
+def gen_network_ff():
+    """The FFMLP backbone (nerf/network_ff.py:51-134 on ffmlp/ffmlp.py:15-168), the configuration the bench renders: density,
+    forward and the masked color() on seeded points, and one eval-mode run_cuda frame, all executed by the reference classes with
+    the table in half (autocast branch) and `_ffmlp` on the oracle.  FFMLP weights: the reference's own initialiser (seed 42)."""
+    bound, H, W = 2, 12, 12
+    sc = SC.StonehengeScene(H=H, W=W, bound=bound)
+    net = _ref_network_ff(bound, True, 48.0)
+    net.density_bitfield = torch.from_numpy(sc.bitfield())
+    g = torch.Generator().manual_seed(9)
+    M = 301                                             # not a multiple of 128: FFMLP pads 1..128 rows (ffmlp.py:157-159)
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * bound
+    x[0], x[1], x[2] = bound, -bound, 0.0
+    d = torch.randn(M, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    mask = torch.rand(M, generator=g) > 0.4
+    with torch.no_grad(), _autocast_on():
+        dens = net.density(x)
+        sigma, rgb = net(x, d)
+        rgb_masked = net.color(x, d, mask=mask, geo_feat=dens["geo_feat"])
+        rgb_none = net.color(x, d, mask=torch.zeros(M, dtype=torch.bool), geo_feat=dens["geo_feat"])
+        rays = ref_get_rays(torch.from_numpy(SC.orbit_poses()[7:8]), SC.intrinsics(H, W), H, W)
+        out = net.render(rays["rays_o"], rays["rays_d"], staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)
+    save("network_ff.npz", bound=bound, H=H, W=W, view=7, density_scale=48.0, table_seed=0, x=x.numpy(), d=d.numpy(), mask=mask.numpy(),
+         sigma=dens["sigma"].numpy(), geo_feat=dens["geo_feat"].numpy(), fwd_sigma=sigma.numpy(), fwd_rgb=rgb.numpy(),
+         rgb_masked=rgb_masked.numpy(), rgb_none=rgb_none.numpy(), sigma_weights=net.sigma_net.weights.detach().numpy(),
+         color_weights=net.color_net.weights.detach().numpy(), image=out["image"].numpy(), depth=out["depth"].numpy(),
+         last_sigmas=out["sigmas"].numpy(), last_rgbs=out["rgbs"].numpy(), bitfield_sha256=SC.bitfield_sha256(sc.bitfield()))
+
+
 def gen_state_dict_keys():
     """Names, shapes and dtypes of the reference model's state dict (what Trainer.save_checkpoint stores under 'model',
     nerf/utils.py:938-998) for the configurations the rollout uses; a checkpoint-compatibility pin, no tensor data."""
     import json
     out = {}
+    from nerf.network_ff import NeRFNetwork as RefFF
     for bound in (1, 2):
         for cuda_ray in (False, True):
             net = RefNetwork(encoding="hashgrid", bound=bound, cuda_ray=cuda_ray, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1)
             out[f"bound{bound}_cuda_ray{int(cuda_ray)}"] = {k: [list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()}
+            net = RefFF(encoding="hashgrid", bound=bound, cuda_ray=cuda_ray, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1)
+            out[f"ff_bound{bound}_cuda_ray{int(cuda_ray)}"] = {k: [list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()}
+    net = RefNetwork(encoding="hashgrid", bound=2, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=32)
+    out["bound2_cuda_ray1_bg32"] = {k: [list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()}
     path = os.path.join(HERE, "state_dict_keys.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
@@ -410,6 +655,10 @@ if __name__ == "__main__":
     gen_state_dict_keys()
     gen_uq()
     gen_rollout()
+    gen_network_ff()
+    gen_sh_literal()
+    gen_density_grid()
+    gen_background()
     # keep the reference tree pristine
     import shutil
     for dirpath, dirnames, _ in os.walk(REF):

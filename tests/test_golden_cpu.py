@@ -133,3 +133,62 @@ def test_uq_restatement_matches_reference_class():
         np.testing.assert_allclose(Hh.oracle_uq_objective(f["c"], f["d"], f["r"], p), want, rtol=2e-5, atol=1e-5)
         closed = np.log(p[1] ** 2 * st["A"]) + (st["R"] - p[0] * st["B"]) ** 2 / (p[1] ** 2 * st["A"])
         np.testing.assert_allclose(closed, want, rtol=2e-5, atol=1e-5)            # the sufficient-statistics form is the same function
+
+
+def _ff_oracle_net(f):
+    bound = int(f["bound"])
+    offsets, pls = Hh.grid_offsets(desired_resolution=2048 * bound)
+    emb16 = seeded_table(int(offsets[-1]), int(f["table_seed"])).astype(np.float16)
+    return Hh.OracleNetwork(emb16, offsets, pls, f["sigma_weights"].astype(np.float16), f["color_weights"].astype(np.float16), bound)
+
+
+def test_ffmlp_backbone_restatement_matches_reference_network_ff():
+    """oracle/driver.py::OracleNetwork (what every GPU parity test of the headline fp16 path is checked against) vs the reference's
+    nerf/network_ff.py + ffmlp/ffmlp.py executed on the same oracle kernels (network_ff.npz): the host glue -- pad-to-128, the
+    h[...,0] / h[...,1:] split, cat([SH, geo_feat, 0]), the masked color() -- is the reference's own code there."""
+    f = load("network_ff.npz")
+    net = _ff_oracle_net(f)
+    sigma, geo = net.density(f["x"])
+    np.testing.assert_allclose(sigma, f["sigma"], rtol=2e-7, atol=0)               # exp of the same fp16 value: numpy vs torch libm
+    assert np.array_equal(geo.astype(np.float32), f["geo_feat"])
+    s2, rgb = net.forward(f["x"], f["d"])
+    np.testing.assert_allclose(s2, f["fwd_sigma"], rtol=2e-7, atol=0)
+    assert f["fwd_rgb"].dtype == np.float16 and f["geo_feat"].dtype == np.float16 and f["sigma"].dtype == np.float32   # dtypes as on the GPU
+    assert np.array_equal(rgb, f["fwd_rgb"])                                       # torch.sigmoid on the half tensor: rounds to half
+    masked = f["rgb_masked"]
+    assert np.array_equal(masked[~f["mask"]], np.zeros_like(masked[~f["mask"]])) and not f["rgb_none"].any()
+    np.testing.assert_allclose(masked[f["mask"]], f["fwd_rgb"][f["mask"]], rtol=0, atol=0)   # color(mask) == forward on the masked rows
+
+
+def test_run_cuda_restatement_matches_reference_with_ffmlp_backbone():
+    """oracle_run_cuda (the eval loop the bench's parity figure and the smoke test use) vs the reference's run_cuda driving the
+    reference's network_ff on the same oracle kernels"""
+    from nerfsafetyvalidation_amd import scene as SC
+    f = load("network_ff.npz")
+    H, W, bound = int(f["H"]), int(f["W"]), int(f["bound"])
+    sc = SC.StonehengeScene(H=H, W=W, bound=bound)
+    assert SC.bitfield_sha256(sc.bitfield()) == str(f["bitfield_sha256"])
+    ro, rd = Hh.pinhole_rays(SC.orbit_poses()[int(f["view"])], SC.intrinsics(H, W), H, W)
+    res = Hh.oracle_run_cuda(_ff_oracle_net(f), ro, rd, sc.bitfield(), bound, sc.cascade, float(f["density_scale"]))
+    img = res["image"] + (1 - res["weights_sum"])[:, None]
+    np.testing.assert_allclose(img, f["image"][0], rtol=0, atol=1e-6)
+    depth = np.clip(res["depth"] - res["nears"], 0, None) / (res["fars"] - res["nears"])
+    np.testing.assert_allclose(depth, f["depth"][0], rtol=0, atol=2e-6)
+    n_alive, n_step = res["schedule"][-1]
+    M = n_alive * n_step
+    assert f["last_sigmas"].shape[0] == M + 128 - M % 128                           # F11
+
+
+@pytest.mark.parametrize("degree", [1, 2, 4, 8])
+def test_sh_against_the_reference_literal_polynomials(degree):
+    """oracle SH (what the HIP kernel is compared with) vs the values of the reference's hard-coded polynomials and partial
+    derivatives (shencoder.cu:51-355 evaluated line by line in float32, sh_literal.npz): constants, signs, ordering, degree cut."""
+    f = load("sh_literal.npz")
+    n, C2 = f["d"].shape[0], degree * degree
+    out, dy = np.empty((n, C2), np.float32), np.empty((n, 3 * C2), np.float32)
+    O.sh_encode_forward(f["d"], out, n, 3, degree, True, dy)
+    np.testing.assert_allclose(out, f["Y"][:, :C2], rtol=2e-6, atol=4e-6)
+    np.testing.assert_allclose(dy.reshape(n, 3, C2), f["dY"][:, :, :C2], rtol=4e-6, atol=4e-5 if degree == 8 else 1e-5)
+    assert out[0, 0] == np.float32(0.28209479177387814)
+    if degree >= 2:   # sign convention of the first band: Y_1 = (-y, z, -x) * 0.4886 (shencoder.cu:53-55)
+        np.testing.assert_allclose(out[3:6, 1:4], np.float32(0.48860251190291987) * np.stack([-f["d"][3:6, 1], f["d"][3:6, 2], -f["d"][3:6, 0]], -1), rtol=1e-6)

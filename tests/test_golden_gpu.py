@@ -243,3 +243,70 @@ def test_uq_gaussian_golden(device):
     assert np.isfinite(mu) and np.isfinite(sg)
     again = GaussianApproximationDensityUncertainty(_t(f["c"], device), _t(f["d"], device), _t(f["r"], device))
     assert again.stats == GaussianApproximationDensityUncertainty(_t(f["c"], device), _t(f["d"], device), _t(f["r"], device)).stats  # deterministic
+
+
+def test_ffmlp_backbone_golden(device):
+    """The headline configuration -- nerf/network_ff.py on ffmlp/ffmlp.py, fp16 under autocast -- against the fixture the
+    REFERENCE's network_ff / FFMLP / run_cuda produced on the oracle kernels (network_ff.npz): operator path and fused kernels."""
+    from nerfsafetyvalidation_amd import scene as SC
+    from nerfsafetyvalidation_amd.nerf.network_ff import NeRFNetwork
+    f = load("network_ff.npz")
+    bound, H, W = int(f["bound"]), int(f["H"]), int(f["W"])
+    net = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, density_scale=float(f["density_scale"]), min_near=0.2, density_thresh=0.01,
+                      bg_radius=-1)
+    g = torch.Generator().manual_seed(int(f["table_seed"]))
+    net.encoder.embeddings.data.copy_((torch.rand(net.encoder.embeddings.shape, generator=g) - 0.5).half().float())
+    # the reference initialiser (seed 42, ffmlp.py:141-144) gives the same blobs here as there
+    assert np.array_equal(net.sigma_net.weights.detach().numpy(), f["sigma_weights"]) and np.array_equal(net.color_net.weights.detach().numpy(), f["color_weights"])
+    sc = SC.StonehengeScene(H=H, W=W, bound=bound)
+    net.density_bitfield.copy_(torch.from_numpy(sc.bitfield()))
+    net = net.to(device).eval()
+    x, d, mask = [torch.from_numpy(f[k]).to(device) for k in ("x", "d", "mask")]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        dens = net.density(x)
+        sigma, rgb = net(x, d)
+        rgb_masked = net.color(x, d, mask=mask, geo_feat=dens["geo_feat"])
+        rgb_none = net.color(x, d, mask=torch.zeros_like(mask), geo_feat=dens["geo_feat"])
+    assert dens["sigma"].dtype == torch.float32 and dens["geo_feat"].dtype == torch.float16 and rgb.dtype == torch.float16
+    # fp16 MFMA with fp32 accumulation vs the oracle's exact-sum model: a hidden unit may land on the other side of a rounding boundary
+    np.testing.assert_allclose(dens["sigma"].cpu().numpy(), f["sigma"], rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(sigma.cpu().numpy(), f["fwd_sigma"], rtol=1e-2, atol=1e-3)
+    assert (dens["geo_feat"].cpu().numpy() == f["geo_feat"]).mean() > 0.8
+    np.testing.assert_allclose(dens["geo_feat"].float().cpu().numpy(), f["geo_feat"].astype(np.float32), rtol=2e-2, atol=4e-3)
+    np.testing.assert_allclose(rgb.float().cpu().numpy(), f["fwd_rgb"].astype(np.float32), rtol=0, atol=3e-3)
+    assert (rgb.cpu().numpy() == f["fwd_rgb"]).mean() > 0.8
+    got_m = rgb_masked.float().cpu().numpy()
+    assert rgb_masked.dtype == torch.float32 and not got_m[~f["mask"]].any() and not rgb_none.any()        # zeros where not asked (network_ff.py:108-113)
+    np.testing.assert_allclose(got_m[f["mask"]], f["rgb_masked"][f["mask"]], rtol=0, atol=3e-3)
+    # the fused encode + MLP kernel on the same points
+    fs, fc = net.fused_model().network_forward(x, d)
+    np.testing.assert_allclose(fs.cpu().numpy(), f["fwd_sigma"], rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(fc.cpu().numpy(), f["fwd_rgb"].astype(np.float32), rtol=0, atol=3e-3)
+    # one eval frame through run_cuda: operator loop and fused loop
+    ro, rd = _rays(f, device)
+    for fused in (False, True):
+        net.fused = fused
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out = net.render(ro, rd, staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024)
+        err = np.abs(out["image"].float().cpu().numpy() - f["image"])
+        derr = np.abs(out["depth"].float().cpu().numpy() - f["depth"])
+        print(f"ffmlp backbone frame, fused={fused}: max |dRGB| {err.max():.2e} mean {err.mean():.2e}, max |ddepth| {derr.max():.2e}")
+        assert err.max() < 2e-3 and err.mean() < 1e-4, (fused, err.max(), err.mean())
+        assert derr.max() < 2e-3
+        assert out["sigmas"].shape == f["last_sigmas"].shape and out["rgbs"].shape == f["last_rgbs"].shape
+    net.fused = True
+
+
+@pytest.mark.parametrize("degree", [1, 3, 4, 8])
+def test_sh_kernel_against_the_reference_literal_polynomials(device, degree):
+    """k_sh_forward<degree> (compile-time recurrences) vs the values of the reference's literal SH lines (sh_literal.npz)"""
+    from nerfsafetyvalidation_amd.shencoder import SHEncoder
+    f = load("sh_literal.npz")
+    C2 = degree * degree
+    d = _t(f["d"], device).requires_grad_(True)
+    y = SHEncoder(degree=degree)(d)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), f["Y"][:, :C2], rtol=2e-6, atol=4e-6)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(degree)).to(device)
+    y.backward(g)
+    want = np.einsum("nc,ndc->nd", g.cpu().numpy().astype(np.float64), f["dY"][:, :, :C2].astype(np.float64))
+    np.testing.assert_allclose(d.grad.cpu().numpy(), want, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want).max())))
