@@ -277,6 +277,9 @@ NGP_API int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const f
 NGP_API int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas,
                         float* rgbs, ngp_stream_t stream);
 
+/* the density half alone (NeRFNetwork.density, nerf/network_ff.py:77-90): sigmas [M] f32, raw trunc_exp output */
+NGP_API int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, float* sigmas, ngp_stream_t stream);
+
 /* NeRFRenderer.run (nerf/renderer.py:125-258) for upsample_steps == 0 and perturb == False with the fp16 network: T uniform
  * samples per ray between nears and fars (lin = the T values of torch.linspace(0, 1, T), device memory), hash grid + sigma net
  * on every sample, transmittance scan, colour net where weight > 1e-4, and the per-ray sums.  Outputs: weights_sum [N],
@@ -287,6 +290,56 @@ NGP_API int ngp_render_uniform(const ngp_model* model, const float* rays_o, cons
                        const float* fars, uint32_t N, uint32_t T, const float* lin, float* weights_sum, float* depth,
                        float* image, float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs,
                        ngp_stream_t stream);
+
+/* ---------------- sample bookkeeping of NeRFRenderer.run (nerf/renderer.py:12-46, 125-258), operator form ---------------- */
+
+/* :148-160.  z_vals [N,T] = nears + (fars - nears) * lin[t] (lin = the T values of torch.linspace(0, 1, T), device memory), plus
+ * (noise[n,t] - 0.5) * (fars - nears) / steps_for_dist when noise != NULL (:153-155; steps_for_dist = num_steps, 0 = T);
+ * xyzs [N,T,3] = min(max(rays_o + rays_d * z, aabb[:3]), aabb[3:]).  With z_in != NULL the positions are given ([N,T], e.g. the
+ * upsampled samples of :181-182) and only xyzs is produced.  aabb_host: 6 floats in host memory. */
+NGP_API int ngp_uniform_samples(const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N, uint32_t T,
+                        uint32_t steps_for_dist, const float* lin, const float* noise, const float* z_in, const float* aabb_host,
+                        float* z_vals, float* xyzs, ngp_stream_t stream);
+/* vector-Jacobian product of the above w.r.t. the rays (what autograd gives for :159-160, ties of the clip split as torch does):
+ * grad_xyzs [N,T,3] -> grad_rays_o, grad_rays_d [N,3] (overwritten).  z_vals carry no gradient (nears / fars are computed under no_grad, :141). */
+NGP_API int ngp_uniform_samples_backward(const float* grad_xyzs, const float* rays_o, const float* rays_d, const float* z_vals, uint32_t N,
+                                 uint32_t T, const float* aabb_host, float* grad_rays_o, float* grad_rays_d, ngp_stream_t stream);
+/* :206-210.  deltas = z[t+1] - z[t] (last: sample_dist[n]); alpha = 1 - exp(-delta * density_scale * sigma);
+ * weights [N,T] = alpha * cumprod(1 - alpha + 1e-15) (exclusive). */
+NGP_API int ngp_transmittance_weights(const float* z_vals, const float* sigmas, const float* sample_dist, uint32_t N, uint32_t T,
+                              float density_scale, float* weights, ngp_stream_t stream);
+/* grad_weights [N,T] -> grad_sigmas [N,T] (overwritten); T <= 4096 */
+NGP_API int ngp_transmittance_weights_backward(const float* grad_weights, const float* z_vals, const float* sigmas, const float* sample_dist,
+                                       uint32_t N, uint32_t T, float density_scale, float* grad_sigmas, ngp_stream_t stream);
+/* sample_pdf (:12-46): bins [N,n_bins], weights [N,n_bins-1], u [n_samples] (u_per_ray == 0, the `det` linspace) or [N,n_samples]
+ * -> samples [N,n_samples].  2 <= n_bins <= 4096. */
+NGP_API int ngp_sample_pdf(const float* bins, const float* weights, uint32_t N, uint32_t n_bins, const float* u, int u_per_ray,
+                   uint32_t n_samples, float* samples, ngp_stream_t stream);
+/* the re-ordering of :190-198 for two runs that are each ascending along the ray: z [N,Ta+Tb] ascending, index [N,Ta+Tb] int64 =
+ * position of every output in cat([z_a, z_b], 1) (ties: z_a first).  Equals torch.sort of the concatenation. */
+NGP_API int ngp_merge_sorted(const float* z_a, const float* z_b, uint32_t N, uint32_t Ta, uint32_t Tb, float* z, int64_t* index,
+                     ngp_stream_t stream);
+
+/* ---------------- density-grid maintenance (nerf/renderer.py:388-544): the producer of density_bitfield ---------------- */
+
+/* mark_untrained_grid (:388-449): cells of density_grid [cascade, H^3] (Morton order) whose centre no camera sees become -1.
+ * poses [n_cams,4,4] cam2world (device).  workspace: only for more than 2048 cameras (cascade * H^3 * 4 bytes), else NULL. */
+NGP_API int ngp_mark_untrained_grid(const float* poses, uint32_t n_cams, float fx, float fy, float cx, float cy, float bound, uint32_t cascade,
+                            uint32_t H, float* density_grid, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* sample positions of update_extra_state (:479-485, :512-520): coords int32 [n,3] cell coordinates, or NULL = every cell in the
+ * reference's meshgrid order (x slowest); cascade_bound = min(2^cas, bound); noise [n,3] uniform [0,1) or NULL (cell centres)
+ * -> xyzs [n,3] = centre * (cascade_bound - hgs) + (noise * 2 - 1) * hgs, indices int32 [n] = morton3D(coords). */
+NGP_API int ngp_density_grid_points(const int32_t* coords, uint32_t n, uint32_t H, float cascade_bound, const float* noise, float* xyzs,
+                            int32_t* indices, ngp_stream_t stream);
+/* :489-491 + :531-532 for one cascade: tmp[indices] = sigmas * density_scale (duplicates: the LAST sample wins, as PyTorch's CPU
+ * index_put_), then grid = max(grid * decay, tmp) where both are >= 0.  workspace: ngp_density_grid_workspace(cascade, H) bytes. */
+NGP_API size_t ngp_density_grid_workspace(uint32_t cascade, uint32_t H);
+NGP_API int ngp_density_grid_update(float* density_grid, uint32_t cascade, uint32_t H, uint32_t cas, const int32_t* indices, const float* sigmas,
+                            uint32_t n, float density_scale, float decay, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
+/* :533-538: mean_thresh[0] = mean(clamp(density_grid, 0)) (summed in double in a fixed order), mean_thresh[1] = min(mean,
+ * density_thresh), bitfield = packbits(density_grid, mean_thresh[1]) -- on the device, no host round trip in between. */
+NGP_API int ngp_density_grid_finish(const float* density_grid, uint32_t cascade, uint32_t H, float density_thresh, float* mean_thresh,
+                            uint8_t* bitfield, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
 /* ---------------- uncertainty/quantification/gaussian_approximation_density_uncertainty.py:24-51 ---------------- */
 

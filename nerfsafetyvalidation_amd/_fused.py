@@ -104,8 +104,23 @@ class FusedModel:
         m.packed_weights = _lib.ptr(self._packed) if self._packed is not None else None
         return m
 
+    def _ensure_packed(self):
+        """the two weight blobs as MFMA fragments, once per snapshot"""
+        if self._packed is not None:
+            return
+        with self._ctx_lock:
+            if self._packed is not None:
+                return
+            lib = _lib.lib()
+            m = self._struct(None)
+            packed = torch.empty(lib.ngp_packed_weights_bytes(), dtype=torch.uint8, device=self.device)
+            _lib.check(lib.ngp_pack_weights(C.byref(m), _lib.ptr(packed), _lib.stream()), "pack_weights")
+            torch.cuda.current_stream(self.device).synchronize()   # other streams may render with it next
+            self._packed = packed
+
     def _ensure_cells(self):
         """Expand the first twelve levels when the budget and a third of the free device memory allow."""
+        self._ensure_packed()
         if self._cells_ready:
             return
         with self._ctx_lock:
@@ -113,9 +128,6 @@ class FusedModel:
                 return
             lib = _lib.lib()
             m = self._struct(None)
-            packed = torch.empty(lib.ngp_packed_weights_bytes(), dtype=torch.uint8, device=self.device)
-            _lib.check(lib.ngp_pack_weights(C.byref(m), _lib.ptr(packed), _lib.stream()), "pack_weights")
-            self._packed = packed
             free, _ = torch.cuda.mem_get_info(self.device)
             budget = min(self.cell_table_gb * (1 << 30), free / 3)
             for n in (12,):          # (the kernels are specialised for exactly twelve expanded levels)
@@ -140,6 +152,17 @@ class FusedModel:
         _lib.check(lib.ngp_network_forward(C.byref(m), _lib.ptr(xyzs), _lib.ptr(dirs), M, _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.stream()),
                    "network_forward")
         return sigmas, rgbs
+
+    def network_density(self, xyzs):
+        """fused NeRFNetwork.density: xyzs [M,3] f32 -> sigma [M] f32 (unscaled).  Does not build the per-cell records (it serves the
+        density-grid maintenance during training, where the snapshot is rebuilt whenever the parameters move)."""
+        xyzs = xyzs.float().contiguous()
+        self._ensure_packed()
+        M = xyzs.shape[0]
+        sigmas = torch.empty(M, dtype=torch.float32, device=xyzs.device)
+        m = self._struct(None)
+        _lib.check(_lib.lib().ngp_network_density(C.byref(m), _lib.ptr(xyzs), M, _lib.ptr(sigmas), _lib.stream()), "network_density")
+        return sigmas
 
     def _pad_value(self):
         """what the network returns for the reference's zero-filled padding rows (xyz = 0, dir = 0)"""

@@ -82,6 +82,18 @@ SIGNATURES = {
     "ngp_render_rays": [_vp, C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                         C.POINTER(C.c_float), C.POINTER(RenderStats), _int, _vp],
     "ngp_network_forward": [C.POINTER(ModelStruct), _vp, _vp, _u32, _vp, _vp, _vp],
+    "ngp_network_density": [C.POINTER(ModelStruct), _vp, _u32, _vp, _vp],
+    "ngp_uniform_samples": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp],
+    "ngp_uniform_samples_backward": [_vp, _vp, _vp, _vp, _u32, _u32, C.POINTER(C.c_float), _vp, _vp, _vp],
+    "ngp_transmittance_weights": [_vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp],
+    "ngp_transmittance_weights_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp],
+    "ngp_sample_pdf": [_vp, _vp, _u32, _u32, _vp, _int, _u32, _vp, _vp],
+    "ngp_merge_sorted": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
+    "ngp_mark_untrained_grid": [_vp, _u32, _f32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _vp, _sz, _vp],
+    "ngp_density_grid_points": [_vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
+    "ngp_density_grid_workspace": [_u32, _u32],
+    "ngp_density_grid_update": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _f32, _f32, _vp, _sz, _vp],
+    "ngp_density_grid_finish": [_vp, _u32, _u32, _f32, _vp, _vp, _vp, _sz, _vp],
     "ngp_render_uniform": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
     "ngp_debug_set_stamps": [_vp],
     "ngp_debug_set_sample_hash": [_vp],
@@ -92,7 +104,7 @@ SIGNATURES = {
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
 _RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
-             "ngp_ffmlp_backward_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
+             "ngp_ffmlp_backward_workspace": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
 
 _lib = None
 

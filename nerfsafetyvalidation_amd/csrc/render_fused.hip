@@ -499,6 +499,27 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
     }
 }
 
+// the density half alone (NeRFNetwork.density, network_ff.py:77-90): what the density-grid maintenance queries (renderer.py:487,526)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_network_density(NetArgs na, GridLevels lv, const float* __restrict__ xyzs, uint32_t M,
+                                                         float* __restrict__ sigmas) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_tiles = (M + 15) / 16;
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t m = tile * 16 + c;
+        const uint32_t mm = m < M ? m : M - 1;
+        float sg;
+        _Float16 s16[4];
+        net_density<MODE>(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], sg, s16);
+        if (lane < 16 && m < M) sigmas[m] = sg;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NeRFRenderer.run, uniform sampling without upsampling (nerf/renderer.py:125-258): the path validate.py -O executes
 // (cuda_ray = False, num_steps = 512).  One wave walks one ray 16 samples at a time: positions from the linspace table,
@@ -1785,6 +1806,28 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
         k_render_uniform<0><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
                                                      dump_begin, sigmas, rgbs, -model->bound, model->bound);
     return check_launch("render_uniform");
+}
+
+int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, float* sigmas, ngp_stream_t stream) {
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(xyzs && sigmas, "network_density: null pointer");
+    NGP_REQUIRE(model && model->packed_weights, "network_density: model->packed_weights is NULL (ngp_pack_weights fills it)");
+    hipStream_t s = (hipStream_t)stream;
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
+    if (rc) return rc;
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<0>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<1>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<2>), 96 * 1024);
+    uint32_t blocks = div_up(div_up(M, 16), 4);
+    if (blocks > 1024) blocks = 1024;
+    ProfScope prof("network_density", s, M);
+    if (needs_generic(lv)) k_network_density<1><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, sigmas);
+    else if (na.cells) k_network_density<2><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, sigmas);
+    else k_network_density<0><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, sigmas);
+    return check_launch("network_density");
 }
 
 int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, float* rgbs,

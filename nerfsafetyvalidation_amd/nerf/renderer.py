@@ -19,35 +19,28 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import raymarching
-from .utils import custom_meshgrid
+from .. import _lib, raymarching
+from . import sampling
+from .sampling import sample_pdf  # noqa: F401  (renderer.py:12-46: importable from here as in the reference)
 
 _STATS_TLS = threading.local()   # per-thread `last_render_stats` of every renderer (keyed by id)
 
 
-def sample_pdf(bins, weights, n_samples, det=False):
-    """Inverse-CDF sampling (renderer.py:12-46).  bins [B,T], weights [B,T-1] -> [B,n_samples]"""
-    weights = weights + 1e-5
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    if det:
-        u = torch.linspace(0. + 0.5 / n_samples, 1. - 0.5 / n_samples, steps=n_samples).to(weights.device)
-        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
-    else:
-        u = torch.rand(list(cdf.shape[:-1]) + [n_samples]).to(weights.device)
-    u = u.contiguous()
-    inds = torch.searchsorted(cdf, u, right=True)
-    below = torch.clamp(inds - 1, min=0)
-    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
-    inds_g = torch.stack([below, above], -1)
-    matched_shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
-    cdf_g = torch.gather(cdf.unsqueeze(1).expand(matched_shape), 2, inds_g)
-    bins_g = torch.gather(bins.unsqueeze(1).expand(matched_shape), 2, inds_g)
-    denom = cdf_g[..., 1] - cdf_g[..., 0]
-    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
-    t = (u - cdf_g[..., 0]) / denom
-    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+class _Draws:
+    """The random numbers update_extra_state consumes, drawn the way the reference draws them (torch generator of the grid's
+    device: randint for cells and picks, rand for the jitter; renderer.py:485,499,503,522).  Tests substitute seeded draws."""
+
+    @staticmethod
+    def cells(H, n, device):
+        return torch.randint(0, H, (n, 3), device=device)
+
+    @staticmethod
+    def picks(count, n, device):
+        return torch.randint(0, count, [n], dtype=torch.long, device=device)
+
+    @staticmethod
+    def jitter(n, device):
+        return torch.rand(n, 3, device=device)
 
 
 class NeRFRenderer(nn.Module):
@@ -131,270 +124,202 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
 
     # ------------------------------------------------------------------ uniform-sample path (renderer.py:125-258)
-    def _weights(self, z_vals, sample_dist, sigma):
-        deltas = z_vals[..., 1:] - z_vals[..., :-1]
-        deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
-        alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
-        alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
-        return deltas, alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
+    def _density_along_rays(self, points):
+        """self.density on [N,T,3] sample positions -> its outputs as [N,T,k]"""
+        N, T = points.shape[:2]
+        return {name: value.view(N, T, -1) for name, value in self.density(points.reshape(-1, 3)).items()}
 
     def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
-        """rays_o, rays_d [B,N,3] (B == 1) -> dict(depth [B,N], image [B,N,3], weights_sum, rgbs, sigmas, aggregated_density)"""
+        """rays_o, rays_d [B,N,3] (B == 1) -> dict(depth [B,N], image [B,N,3], weights_sum, rgbs, sigmas, aggregated_density).
+        Operator form (differentiable; the eval-mode, no-upsampling case of a staged render goes through one fused launch
+        instead, _render_staged_fused): the network is self.density / self.color, everything between the network calls is a
+        native launch of nerf/sampling.py."""
         prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
-        N = rays_o.shape[0]
-        device = rays_o.device
-        aabb = self.aabb_train if self.training else self.aabb_infer
-
+        origins, directions = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        N = origins.shape[0]
+        box = self.aabb_train if self.training else self.aabb_infer
         with torch.no_grad():
-            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
-        nears = nears.unsqueeze(-1)
-        fars = fars.unsqueeze(-1)
+            nears, fars = raymarching.near_far_from_aabb(origins, directions, box, self.min_near)
+        span = fars - nears
+        last_interval = span / num_steps                                           # renderer.py:153, also the last delta after upsampling
+        jitter = torch.rand(N, num_steps, device=origins.device) if perturb else None
+        depths, points = sampling.uniform_samples(origins, directions, nears, fars, num_steps, box, jitter)
+        field = self._density_along_rays(points)
 
-        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand((N, num_steps))
-        z_vals = nears + (fars - nears) * z_vals
-        sample_dist = (fars - nears) / num_steps
-        if perturb:
-            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
-
-        xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_vals.unsqueeze(-1)
-        xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
-
-        density_outputs = self.density(xyzs.reshape(-1, 3))
-        for k, v in density_outputs.items():
-            density_outputs[k] = v.view(N, num_steps, -1)
-
-        if upsample_steps > 0:  # renderer.py:172-204
+        if upsample_steps > 0:                                                     # renderer.py:172-204
             with torch.no_grad():
-                deltas, weights = self._weights(z_vals, sample_dist, density_outputs["sigma"].squeeze(-1))
-                z_vals_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
-                new_z_vals = sample_pdf(z_vals_mid, weights[:, 1:-1], upsample_steps, det=not self.training).detach()
-                new_xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * new_z_vals.unsqueeze(-1)
-                new_xyzs = torch.min(torch.max(new_xyzs, aabb[:3]), aabb[3:])
-            new_density_outputs = self.density(new_xyzs.reshape(-1, 3))
-            for k, v in new_density_outputs.items():
-                new_density_outputs[k] = v.view(N, upsample_steps, -1)
-            z_vals = torch.cat([z_vals, new_z_vals], dim=1)
-            z_vals, z_index = torch.sort(z_vals, dim=1)
-            xyzs = torch.cat([xyzs, new_xyzs], dim=1)
-            xyzs = torch.gather(xyzs, dim=1, index=z_index.unsqueeze(-1).expand_as(xyzs))
-            for k in density_outputs:
-                tmp_output = torch.cat([density_outputs[k], new_density_outputs[k]], dim=1)
-                density_outputs[k] = torch.gather(tmp_output, dim=1, index=z_index.unsqueeze(-1).expand_as(tmp_output))
+                coarse = sampling.transmittance_weights(depths, field["sigma"][..., 0], last_interval, self.density_scale)
+                gaps = depths[:, 1:] - depths[:, :-1]
+                centres = depths[:, :-1] + 0.5 * gaps
+                fine_depths = sampling.sample_pdf(centres, coarse[:, 1:-1], upsample_steps, det=not self.training)
+                fine_points = sampling.samples_at(origins, directions, fine_depths, box)
+            fine_field = self._density_along_rays(fine_points)
+            depths, order = sampling.merge_sorted(depths, fine_depths)             # = sort(cat(...)) of the reference, both runs ascending
+            pick = order.unsqueeze(-1)
+            points = torch.take_along_dim(torch.cat([points, fine_points], dim=1), pick, dim=1)
+            field = {name: torch.take_along_dim(torch.cat([field[name], fine_field[name]], dim=1), pick, dim=1) for name in field}
 
-        _, weights = self._weights(z_vals, sample_dist, density_outputs["sigma"].squeeze(-1))
-
-        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
-        for k, v in density_outputs.items():
-            density_outputs[k] = v.view(-1, v.shape[-1])
-
-        mask = weights > 1e-4  # hard coded in the reference (:216)
-        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **density_outputs)
-        rgbs = rgbs.view(N, -1, 3)
+        sigma = field["sigma"][..., 0]
+        weights = sampling.transmittance_weights(depths, sigma, last_interval, self.density_scale)
+        flat = {name: value.reshape(-1, value.shape[-1]) for name, value in field.items()}
+        view_dirs = directions.unsqueeze(1).expand_as(points).reshape(-1, 3)
+        rgbs = self.color(points.reshape(-1, 3), view_dirs, mask=(weights > 1e-4).reshape(-1), **flat).view(N, -1, 3)   # :216, hard coded
 
         weights_sum = weights.sum(dim=-1)
-        ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
-        depth = torch.sum(weights * ori_z_vals, dim=-1)
-        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
-
-        if self.bg_radius > 0:
-            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
-            bg_color = self.background(sph, rays_d.reshape(-1, 3))
-        elif bg_color is None:
-            bg_color = 1
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-
-        image = image.view(*prefix, 3)
-        depth = depth.view(*prefix)
-        aggregated_density = torch.sum(weights * density_outputs["sigma"].view(*weights.shape), dim=1).view(*prefix)
+        relative = ((depths - nears.unsqueeze(-1)) / span.unsqueeze(-1)).clamp(0, 1)
+        depth = (weights * relative).sum(dim=-1)
+        image = (weights.unsqueeze(-1) * rgbs).sum(dim=-2)
+        image = image + (1 - weights_sum).unsqueeze(-1) * self._backdrop(origins, directions, bg_color)
         return {
-            "depth": depth,
-            "image": image,
+            "depth": depth.view(*prefix),
+            "image": image.view(*prefix, 3),
             "weights_sum": weights_sum,
             "rgbs": rgbs,
-            "sigmas": density_outputs["sigma"],
-            "aggregated_density": aggregated_density,
+            "sigmas": flat["sigma"],
+            "aggregated_density": (weights * sigma).sum(dim=1).view(*prefix),
         }
 
     # ------------------------------------------------------------------ occupancy-grid path (renderer.py:261-386)
-    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, **kwargs):
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
-        N = rays_o.shape[0]
-        device = rays_o.device
-
-        with torch.no_grad():
-            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer,
-                                                         self.min_near)
+    def _backdrop(self, origins, directions, bg_color):
+        """what shows behind the volume: the environment-map network (renderer.py:277-280), the caller's colour, or white"""
         if self.bg_radius > 0:
-            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
-            bg_color = self.background(sph, rays_d)
-        elif bg_color is None:
-            bg_color = 1
+            return self.background(raymarching.sph_from_ray(origins, directions, self.bg_radius), directions)
+        return 1 if bg_color is None else bg_color
 
-        results = {}
-        if self.training:
-            counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
-            self.local_step += 1
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb,
-                                                                    128, force_all_rays, dt_gamma, max_steps)
-            sigmas, rgbs = self(xyzs, dirs)
-            sigmas = self.density_scale * sigmas
-            if len(sigmas.shape) == 2:  # CCNeRF residual learning (renderer.py:303-317)
-                depths, images = [], []
-                for k in range(sigmas.shape[0]):
-                    weights_sum, depth, image = raymarching.composite_rays_train(sigmas[k], rgbs[k], deltas, rays)
-                    image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-                    depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-                    images.append(image.view(*prefix, 3))
-                    depths.append(depth.view(*prefix))
-                depth = torch.stack(depths, axis=0)
-                image = torch.stack(images, axis=0)
-            else:
-                weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays)
-                image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-                depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-                image = image.view(*prefix, 3)
-                depth = depth.view(*prefix)
-            results["weights_sum"] = weights_sum
-        else:
-            fm = self.fused_model() if self.fused else None
-            if fm is not None and not torch.is_grad_enabled():
-                weights_sum, depth, image, sigmas, rgbs = fm.render(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb,
-                                                                    want_last=self.return_last_tensors,
-                                                                    frame_width=kwargs.get("frame_width", 0))
-                self.last_render_stats = fm.last_stats
-            else:
-                weights_sum, depth, image, sigmas, rgbs = self._march_composite_loop(rays_o, rays_d, nears, fars, dt_gamma,
-                                                                                     max_steps, perturb)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-            image = image.view(*prefix, 3)
-            depth = depth.view(*prefix)
+    def _march_train(self, origins, directions, nears, fars, dt_gamma, max_steps, perturb, force_all_rays):
+        """training branch (renderer.py:286-327): one march over all rays, one network call, one differentiable compositing"""
+        counter = self.step_counter[self.local_step % 16]      # ring of the last 16 steps' sample counts (-> mean_count)
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(origins, directions, self.bound, self.density_bitfield, self.cascade,
+                                                                self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                force_all_rays, dt_gamma, max_steps)
+        sigmas, rgbs = self(xyzs, dirs)
+        sigmas = self.density_scale * sigmas
+        if sigmas.dim() != 1:
+            raise RuntimeError("run_cuda: the network must return one density per sample (residual stacks are not part of this path)")
+        return (*raymarching.composite_rays_train(sigmas, rgbs, deltas, rays), sigmas, rgbs)
 
-        results["depth"] = depth
-        results["image"] = image
-        results["sigmas"] = sigmas
-        results["rgbs"] = rgbs
-        return results
-
-    def _march_composite_loop(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, perturb):
-        """The reference's eval loop, operator by operator (renderer.py:337-373)."""
-        N, device = rays_o.shape[0], rays_o.device
-        weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
+    def _march_eval_operators(self, origins, directions, nears, fars, dt_gamma, max_steps, perturb):
+        """eval branch, operator by operator (renderer.py:337-373) -- what the fused renderer (ngp_render_rays) replaces and is
+        tested against: march up to n_step samples for the rays still alive, evaluate them, composite in place, drop the rays
+        that saturated or left the box, repeat with n_step = clamp(N // n_alive, 1, 8)."""
+        N, device = origins.shape[0], origins.device
+        acc = torch.zeros(N, dtype=torch.float32, device=device)
         depth = torch.zeros(N, dtype=torch.float32, device=device)
         image = torch.zeros(N, 3, dtype=torch.float32, device=device)
-        rays_alive = torch.arange(N, dtype=torch.int32, device=device)
-        rays_t = nears.clone()
+        alive = torch.arange(N, dtype=torch.int32, device=device)
+        t_now = nears.clone()
         sigmas = rgbs = None
-        step = 0
-        self.last_render_stats = {"iterations": 0, "samples_slots": 0}
-        while step < max_steps:
-            n_alive = rays_alive.shape[0]
-            if n_alive <= 0:
-                break
+        stats = {"iterations": 0, "samples_slots": 0}
+        marched = 0
+        while marched < max_steps and alive.shape[0] > 0:
+            n_alive = alive.shape[0]
             n_step = max(min(N // n_alive, 8), 1)
-            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
-                                                        self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
-                                                        perturb, dt_gamma, max_steps)
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, alive, t_now, origins, directions, self.bound, self.density_bitfield,
+                                                        self.cascade, self.grid_size, nears, fars, 128, perturb, dt_gamma, max_steps)
             sigmas, rgbs = self(xyzs, dirs)
             sigmas = self.density_scale * sigmas
-            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
-            rays_alive = rays_alive[rays_alive >= 0]
-            step += n_step
-            self.last_render_stats["iterations"] += 1
-            self.last_render_stats["samples_slots"] += n_alive * n_step
-        return weights_sum, depth, image, sigmas, rgbs
+            raymarching.composite_rays(n_alive, n_step, alive, t_now, sigmas, rgbs, deltas, acc, depth, image)
+            alive = alive[alive >= 0]                           # composite_rays marks finished rays with -1
+            marched += n_step
+            stats["iterations"] += 1
+            stats["samples_slots"] += n_alive * n_step
+        self.last_render_stats = stats
+        return acc, depth, image, sigmas, rgbs
+
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, **kwargs):
+        """rays_o, rays_d [B,N,3] (B == 1) -> dict(depth [B,N], image [B,N,3], sigmas, rgbs (+ weights_sum when training))"""
+        prefix = rays_o.shape[:-1]
+        origins, directions = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        with torch.no_grad():
+            nears, fars = raymarching.near_far_from_aabb(origins, directions, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        backdrop = self._backdrop(origins, directions, bg_color)
+        out = {}
+        if self.training:
+            acc, depth, image, sigmas, rgbs = self._march_train(origins, directions, nears, fars, dt_gamma, max_steps, perturb, force_all_rays)
+            out["weights_sum"] = acc
+        else:
+            fm = self.fused_model() if self.fused and not torch.is_grad_enabled() else None
+            if fm is not None:
+                acc, depth, image, sigmas, rgbs = fm.render(self, origins, directions, nears, fars, dt_gamma, max_steps, perturb,
+                                                            want_last=self.return_last_tensors, frame_width=kwargs.get("frame_width", 0))
+                self.last_render_stats = fm.last_stats
+            else:
+                acc, depth, image, sigmas, rgbs = self._march_eval_operators(origins, directions, nears, fars, dt_gamma, max_steps, perturb)
+        image = image + (1 - acc).unsqueeze(-1) * backdrop
+        depth = (depth - nears).clamp(min=0) / (fars - nears)    # renderer.py:326 / :376
+        out.update(depth=depth.view(*prefix), image=image.view(*prefix, 3), sigmas=sigmas, rgbs=rgbs)
+        return out
 
     # ------------------------------------------------------------------ density grid maintenance (renderer.py:388-544)
+    def _grid_workspace(self):
+        nbytes = _lib.lib().ngp_density_grid_workspace(self.cascade, self.grid_size)
+        return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=self.density_grid.device), nbytes
+
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """Cells no training camera sees become -1 in density_grid (renderer.py:388-449).  poses [B,4,4] cam2world, intrinsic
+        (fx, fy, cx, cy).  One launch over all cells and cascades (csrc/density_grid.hip); `S`, the reference's block size of its
+        Python loops, has no role here."""
         if not self.cuda_ray:
             return
-        if isinstance(poses, np.ndarray):
-            poses = torch.from_numpy(poses)
-        B = poses.shape[0]
-        fx, fy, cx, cy = intrinsic
-        dev = self.density_bitfield.device
-        axes = [torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S) for _ in range(3)]
-        count = torch.zeros_like(self.density_grid)
-        poses = poses.to(count.device)
-        for xs in axes[0]:
-            for ys in axes[1]:
-                for zs in axes[2]:
-                    xx, yy, zz = custom_meshgrid(xs, ys, zs)
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    world_xyzs = (2 * coords.float() / (self.grid_size - 1) - 1).unsqueeze(0)
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / self.grid_size
-                        cas_world_xyzs = world_xyzs * (bound - half_grid_size)
-                        head = 0
-                        while head < B:
-                            tail = min(head + S, B)
-                            cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
-                            cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
-                            mask_z = cam_xyzs[:, :, 2] > 0
-                            mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask = (mask_z & mask_x & mask_y).sum(0).reshape(-1)
-                            count[cas, indices] += mask
-                            head += S
-        self.density_grid[count == 0] = -1
+        device = self.density_grid.device
+        cams = torch.as_tensor(np.asarray(poses) if not torch.is_tensor(poses) else poses, dtype=torch.float32).to(device).contiguous()
+        fx, fy, cx, cy = [float(v) for v in intrinsic]
+        work, nbytes = self._grid_workspace()
+        _lib.check(_lib.lib().ngp_mark_untrained_grid(_lib.ptr(cams), cams.shape[0], fx, fy, cx, cy, float(self.bound), self.cascade, self.grid_size,
+                                                      _lib.ptr(self.density_grid), _lib.ptr(work), nbytes, _lib.stream()), "mark_untrained_grid")
+
+    def _grid_sigmas(self, points):
+        """density of the grid's sample points [n,3] -> sigma [n] f32: the fused encode + sigma-net kernel when the model has one
+        (fp16 backbone under autocast), else the network's own density()"""
+        fm = None
+        if self.fused and torch.is_autocast_enabled("cuda"):
+            fm = self.fused_model()
+        if fm is not None:
+            return fm.network_density(points)
+        return self.density(points)["sigma"].reshape(-1).detach().float().contiguous()
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
+        """Refresh density_grid -> density_bitfield from the current network (renderer.py:453-544): the first 16 calls sample every
+        cell, later ones a random quarter plus a quarter drawn from the occupied cells; EMA-max with `decay`; threshold
+        min(mean, density_thresh); packbits.  Per cascade: one launch builds the jittered sample positions, the network gives
+        sigma, two launches apply it; mean, threshold and the bitfield follow without a host round trip."""
         if not self.cuda_ray:
             return
-        tmp_grid = -torch.ones_like(self.density_grid)
-        dev = self.density_bitfield.device
-
-        def query(coords, indices, cas):
-            xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-            bound = min(2 ** cas, self.bound)
-            half_grid_size = bound / self.grid_size
-            cas_xyzs = xyzs * (bound - half_grid_size)
-            cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-            sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
-            sigmas *= self.density_scale
-            tmp_grid[cas, indices] = sigmas.to(tmp_grid.dtype)
-
-        if self.iter_density < 16:  # full sweep (renderer.py:467-492)
-            axes = [torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S) for _ in range(3)]
-            for xs in axes[0]:
-                for ys in axes[1]:
-                    for zs in axes[2]:
-                        xx, yy, zz = custom_meshgrid(xs, ys, zs)
-                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                        indices = raymarching.morton3D(coords).long()
-                        for cas in range(self.cascade):
-                            query(coords, indices, cas)
-        else:  # partial update (renderer.py:496-523)
-            n = self.grid_size ** 3 // 4
-            for cas in range(self.cascade):
-                coords = torch.randint(0, self.grid_size, (n, 3), device=dev)
-                indices = raymarching.morton3D(coords).long()
-                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                rand_mask = torch.randint(0, occ_indices.shape[0], [n], dtype=torch.long, device=dev)
-                occ_indices = occ_indices[rand_mask]
-                occ_coords = raymarching.morton3D_invert(occ_indices)
-                query(torch.cat([coords, occ_coords], dim=0), torch.cat([indices, occ_indices], dim=0), cas)
-
-        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        lib, H, device = _lib.lib(), self.grid_size, self.density_grid.device
+        work, nbytes = self._grid_workspace()
+        sweep = self.iter_density < 16
+        for cas in range(self.cascade):
+            if sweep:                                                             # :467-492
+                coords, n = None, H ** 3
+            else:                                                                 # :496-523
+                quarter = H ** 3 // 4
+                drawn = _Draws.cells(H, quarter, device)
+                occupied = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                chosen = occupied[_Draws.picks(occupied.shape[0], quarter, device)]
+                coords = torch.cat([drawn.int(), raymarching.morton3D_invert(chosen)], dim=0).contiguous()
+                n = coords.shape[0]
+            noise = _Draws.jitter(n, device).float().contiguous()
+            points = torch.empty(n, 3, dtype=torch.float32, device=device)
+            cells = torch.empty(n, dtype=torch.int32, device=device)
+            _lib.check(lib.ngp_density_grid_points(_lib.ptr(coords), n, H, float(min(2 ** cas, self.bound)), _lib.ptr(noise), _lib.ptr(points),
+                                                   _lib.ptr(cells), _lib.stream()), "density_grid_points")
+            sigmas = self._grid_sigmas(points)
+            _lib.check(lib.ngp_density_grid_update(_lib.ptr(self.density_grid), self.cascade, H, cas, _lib.ptr(cells), _lib.ptr(sigmas), n,
+                                                   float(self.density_scale), float(decay), _lib.ptr(work), nbytes, _lib.stream()),
+                       "density_grid_update")
+        mean_thresh = torch.empty(2, dtype=torch.float32, device=device)
+        _lib.check(lib.ngp_density_grid_finish(_lib.ptr(self.density_grid), self.cascade, H, float(self.density_thresh), _lib.ptr(mean_thresh),
+                                               _lib.ptr(self.density_bitfield), _lib.ptr(work), nbytes, _lib.stream()), "density_grid_finish")
+        self.mean_density = mean_thresh[0].item()                                  # the one synchronisation (:533)
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
 
-        total_step = min(16, self.local_step)
-        if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        recent = min(16, self.local_step)                                          # :541-544: running mean of the samples per training step
+        if recent > 0:
+            self.mean_count = int(self.step_counter[:recent, 0].sum().item() / recent)
         self.local_step = 0
 
     # ------------------------------------------------------------------ chunked entry point (renderer.py:549-588)
@@ -423,28 +348,23 @@ class NeRFRenderer(nn.Module):
                 "aggregated_density": torch.stack(agg, 0)}
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
-        _run = self.run_cuda if self.cuda_ray else self.run
-        B, N = rays_o.shape[:2]
-        device = rays_o.device
-        if staged and not self.cuda_ray and self.fused and not torch.is_grad_enabled() and self.bg_radius <= 0 \
-                and kwargs.get("upsample_steps", 128) == 0 and not kwargs.get("perturb", False):
+        """rays_o, rays_d [B,N,3] -> result dict of run / run_cuda.  `staged` (uniform-sample path only) renders max_ray_batch rays
+        at a time and returns depth / image / aggregated_density of all rays with the rgbs / sigmas of the LAST chunk (SURVEY F8:
+        the reference's loop overwrites them, and uncertain.py:80-88 consumes exactly those)."""
+        if self.cuda_ray or not staged:
+            return (self.run_cuda if self.cuda_ray else self.run)(rays_o, rays_d, **kwargs)
+        if self.fused and not torch.is_grad_enabled() and self.bg_radius <= 0 and kwargs.get("upsample_steps", 128) == 0 \
+                and not kwargs.get("perturb", False):
             fm = self.fused_model()
             if fm is not None and self._aabb_is_cube():
                 return self._render_staged_fused(fm, rays_o, rays_d, max_ray_batch, **kwargs)
-        if staged and not self.cuda_ray:
-            depth = torch.empty((B, N), device=device)
-            image = torch.empty((B, N, 3), device=device)
-            aggregated_density = torch.empty((B, N), device=device)
-            for b in range(B):
-                head = 0
-                while head < N:
-                    tail = min(head + max_ray_batch, N)
-                    results_ = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
-                    depth[b:b + 1, head:tail] = results_["depth"]
-                    image[b:b + 1, head:tail] = results_["image"]
-                    aggregated_density[b:b + 1, head:tail] = results_["aggregated_density"]
-                    head += max_ray_batch
-            # rgbs / sigmas come from the LAST chunk only (F8; uncertain.py consumes exactly these)
-            return {"depth": depth, "image": image, "rgbs": results_["rgbs"], "sigmas": results_["sigmas"],
-                    "aggregated_density": aggregated_density}
-        return _run(rays_o, rays_d, **kwargs)
+        n_cams, n_rays = rays_o.shape[:2]
+        per_camera = []
+        for cam in range(n_cams):
+            chunks = [self.run(rays_o[cam:cam + 1, start:start + max_ray_batch], rays_d[cam:cam + 1, start:start + max_ray_batch], **kwargs)
+                      for start in range(0, n_rays, max_ray_batch)]
+            per_camera.append({key: torch.cat([c[key] for c in chunks], dim=1) for key in ("depth", "image", "aggregated_density")})
+            last = chunks[-1]
+        merged = {key: torch.cat([c[key] for c in per_camera], dim=0) for key in ("depth", "image", "aggregated_density")}
+        merged.update(rgbs=last["rgbs"], sigmas=last["sigmas"])
+        return merged

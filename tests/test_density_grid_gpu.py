@@ -1,0 +1,112 @@
+"""Density-grid maintenance (csrc/density_grid.hip behind NeRFRenderer.mark_untrained_grid / update_extra_state) against the
+fixture the REFERENCE's renderer produced (tests/golden/density_grid.npz, make_golden.py::gen_density_grid): a 32^3 x 2 grid,
+seven cameras, two full sweeps and one partial update with the random draws replayed from the stored seeds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _model(f, device):
+    from nerfsafetyvalidation_amd.nerf.network import NeRFNetwork
+    H = int(f["grid_size"])
+    net = NeRFNetwork(encoding="hashgrid", bound=int(f["bound"]), cuda_ray=True, density_scale=float(f["density_scale"]), min_near=0.2,
+                      density_thresh=0.01, bg_radius=-1)
+    g = torch.Generator().manual_seed(int(f["table_seed"]))
+    net.encoder.embeddings.data.copy_((torch.rand(net.encoder.embeddings.shape, generator=g) - 0.5).half().float())
+    for i, l in enumerate(net.sigma_net):
+        l.weight.data.copy_(torch.from_numpy(f[f"sigma{i}"]))
+    for i, l in enumerate(net.color_net):
+        l.weight.data.copy_(torch.from_numpy(f[f"color{i}"]))
+    net.grid_size = H                                       # the renderer reads grid_size and the buffers' shapes everywhere (as the reference)
+    net.density_grid = torch.zeros(net.cascade, H ** 3)
+    net.density_bitfield = torch.zeros(net.cascade * H ** 3 // 8, dtype=torch.uint8)
+    return net.to(device).eval()
+
+
+def test_mark_untrained_grid_golden(device):
+    f = np.load(os.path.join(G, "density_grid.npz"))
+    net = _model(f, device)
+    net.mark_untrained_grid(f["poses"], f["intrinsics"], S=16)
+    got = net.density_grid.cpu().numpy()
+    assert set(np.unique(got)) <= {-1.0, 0.0}
+    mism = int((got != f["marked"]).sum())
+    # (camera-space coordinates through fmaf chains here, a batched matmul in the reference: a cell exactly on a frustum plane of
+    #  EVERY camera that sees it could flip; none does on this fixture)
+    assert mism == 0, mism
+    assert 0.1 < (got == -1).mean() < 0.5
+    net.mark_untrained_grid(torch.from_numpy(f["poses"][:2]).to(device), tuple(f["intrinsics"]), S=64)   # tensor poses on the device, fewer cameras
+    assert int((net.density_grid.cpu().numpy() != f["marked2"]).sum()) == 0
+    # no cameras at all: nothing is seen
+    net.density_grid.zero_()
+    net.mark_untrained_grid(np.zeros((0, 4, 4), np.float32), f["intrinsics"])
+    assert bool((net.density_grid == -1).all())
+
+
+def test_update_extra_state_golden(device):
+    from nerfsafetyvalidation_amd.nerf import renderer as R
+    f = np.load(os.path.join(G, "density_grid.npz"))
+    net = _model(f, device)
+    net.density_grid.copy_(torch.from_numpy(np.where(f["marked"] == -1, -1.0, 0.0).astype(np.float32)).to(device))
+    net.step_counter[:3, 0] = torch.tensor([4096, 8192, 1000], dtype=torch.int32, device=device)
+    net.local_step = 3
+
+    class Replay:      # the reference drew from torch's CPU generator (rand_like / randint): the same draws, in the same order
+        @staticmethod
+        def cells(H, n, dev):
+            return torch.randint(0, H, (n, 3)).to(dev)
+
+        @staticmethod
+        def picks(count, n, dev):
+            return torch.randint(0, count, [n], dtype=torch.long).to(dev)
+
+        @staticmethod
+        def jitter(n, dev):
+            return torch.rand(n, 3).to(dev)
+
+    keep, R._Draws = R._Draws, Replay
+    try:
+        for tag, it in (("full1", 0), ("full2", 1), ("partial", 16)):
+            net.iter_density = it
+            torch.manual_seed(int(f[f"{tag}_seed"]))
+            net.update_extra_state(decay=0.95, S=128)
+            got, want = net.density_grid.cpu().numpy(), f[f"{tag}_grid"]
+            assert np.array_equal(got == -1, want == -1), tag                     # untrained cells stay -1
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=tag)   # fp32 network on both sides (device expf vs libm)
+            assert abs(net.mean_density - float(f[f"{tag}_mean"])) < 1e-5 * float(f[f"{tag}_mean"])
+            bits_got, bits_want = np.unpackbits(net.density_bitfield.cpu().numpy()), np.unpackbits(f[f"{tag}_bitfield"])
+            assert (bits_got != bits_want).mean() < 1e-4, tag                      # a cell within rounding of the threshold may flip
+            assert net.iter_density == it + 1 and net.local_step == 0
+            assert net.mean_count == int(f[f"{tag}_mean_count"])
+            if tag == "full1":                                                     # (only the first call sees a non-empty step-counter ring)
+                assert net.mean_count == (4096 + 8192 + 1000) // 3
+    finally:
+        R._Draws = keep
+    # the partial update only touched sampled cells: most cells kept the previous value, the rest moved
+    changed = (f["partial_grid"] != f["full2_grid"]).mean()
+    assert 0.1 < changed < 0.6
+
+
+def test_update_extra_state_through_the_fused_density_kernel(device):
+    """fp16 backbone under autocast: update_extra_state queries sigma through ngp_network_density (no per-cell records are built);
+    the result agrees with the same sweep through the network's own density() up to the fp16 network's noise"""
+    from nerfsafetyvalidation_amd.scene import StonehengeScene
+    sc = StonehengeScene(H=16, W=16, bound=2)
+    a = sc.build_model(device)
+    b = sc.build_model(device)
+    b.fused = False
+    for m in (a, b):
+        m.density_grid.zero_()
+        m.iter_density = 0
+        torch.manual_seed(3)
+        with torch.autocast("cuda", dtype=torch.float16):
+            m.update_extra_state()
+    assert a._fused_cache is not None and a._fused_cache._cells is None and b._fused_cache is None
+    ga, gb = a.density_grid.cpu().numpy(), b.density_grid.cpu().numpy()
+    np.testing.assert_allclose(ga, gb, rtol=3e-2, atol=1e-3)
+    assert abs(a.mean_density - b.mean_density) < 1e-2 * b.mean_density
+    assert (np.unpackbits(a.density_bitfield.cpu().numpy()) != np.unpackbits(b.density_bitfield.cpu().numpy())).mean() < 5e-3
