@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
         const float dx = rays_d[(size_t)ray * 3], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
         const float near = nears[ray], far = fars[ray];
         const float span = far - near;
-        const float sample_dist = span / (float)T;                                  // :153
+        const float sample_dist = span * (1.0f / (float)T);                          // :153 (tensor / Python scalar on the GPU = multiplication with the fp32 reciprocal)
         const bool dump = sigmas != nullptr && ray >= dump_begin;
         float carry = 1.0f;                                                          // cumprod of (1 - alpha + 1e-15) over earlier tiles
         float a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;             // per-lane partial sums (lanes 0..15)

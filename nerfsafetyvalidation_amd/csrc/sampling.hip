@@ -37,7 +37,9 @@ __global__ void __launch_bounds__(kSmpBlock) k_uniform_samples(const float* __re
     } else {
         const float near = nears[n], far = fars[n];
         z = near + (far - near) * lin[t];                                     // :150
-        if (noise) z = z + (noise[i] - 0.5f) * ((far - near) / (float)steps_for_dist);   // :153-155
+        // :153-155.  sample_dist = (fars - nears) / num_steps: torch divides a GPU tensor by a Python scalar as a multiplication
+        // with the fp32 reciprocal (the reference's CUDA build does the same) -- one bit from the division for non-powers of two
+        if (noise) z = z + (noise[i] - 0.5f) * ((far - near) * (1.0f / (float)steps_for_dist));
         z_vals[i] = z;
     }
     const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};

@@ -76,10 +76,29 @@ def test_update_extra_state_golden(device):
             net.update_extra_state(decay=0.95, S=128)
             got, want = net.density_grid.cpu().numpy(), f[f"{tag}_grid"]
             assert np.array_equal(got == -1, want == -1), tag                     # untrained cells stay -1
-            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=tag)   # fp32 network on both sides (device expf vs libm)
-            assert abs(net.mean_density - float(f[f"{tag}_mean"])) < 1e-5 * float(f[f"{tag}_mean"])
+            dup = np.zeros_like(got, dtype=bool)
+            if tag == "partial":
+                # Cells drawn more than once in a partial update: the reference's `tmp_grid[cas, indices] = sigmas` with duplicate
+                # indices is a race between PyTorch's CPU threads (neither first- nor last-wins); this build lets the LAST sample win.
+                # Replay the draws to find those cells and compare everything else.
+                from nerfsafetyvalidation_amd import raymarching
+                H = int(f["grid_size"])
+                torch.manual_seed(int(f[f"{tag}_seed"]))
+                prev = torch.from_numpy(f["full2_grid"])
+                for cas in range(net.cascade):
+                    drawn = Replay.cells(H, H ** 3 // 4, "cpu")
+                    occupied = torch.nonzero(prev[cas] > 0).squeeze(-1)
+                    chosen = occupied[Replay.picks(occupied.shape[0], H ** 3 // 4, "cpu")]
+                    Replay.jitter(H ** 3 // 2, "cpu")
+                    idx = torch.cat([raymarching.morton3D(drawn.int().to(device)).long().cpu(), chosen])
+                    cells_, counts = torch.unique(idx, return_counts=True)
+                    dup[cas, cells_[counts > 1].numpy()] = True
+                assert 0.02 < dup.mean() < 0.3
+                assert ((np.abs(got - want) > 1e-5) & ~dup).sum() == 0
+            np.testing.assert_allclose(got[~dup], want[~dup], rtol=2e-5, atol=2e-6, err_msg=tag)   # fp32 network on both sides (device expf vs libm)
+            assert abs(net.mean_density - float(f[f"{tag}_mean"])) < (1e-5 if tag != "partial" else 2e-3) * float(f[f"{tag}_mean"])
             bits_got, bits_want = np.unpackbits(net.density_bitfield.cpu().numpy()), np.unpackbits(f[f"{tag}_bitfield"])
-            assert (bits_got != bits_want).mean() < 1e-4, tag                      # a cell within rounding of the threshold may flip
+            assert (bits_got != bits_want).mean() < (1e-4 if tag != "partial" else 2e-2), tag   # a cell within rounding of the threshold may flip (+ the raced cells)
             assert net.iter_density == it + 1 and net.local_step == 0
             assert net.mean_count == int(f[f"{tag}_mean_count"])
             if tag == "full1":                                                     # (only the first call sees a non-empty step-counter ring)

@@ -71,12 +71,11 @@ def test_rollout_against_the_oracle_loop(device):
             # the optimiser: the product minimises the closed form on its one-pass statistics; the reference's objective as
             # written (float64), minimised the same way on the product's OWN samples.  The objective has no minimum in sigma_d
             # (log(s^2 A) -> -inf as s -> 0 once mu = R / B): both runs end where BFGS's gradient tolerance stops them, close to
-            # each other but not at a common point -- mu is well determined, sigma and the objective value only roughly
+            # each other in mu (well determined) but not in sigma or in the objective value reached
             mu_w, sigma_w, _ = Hh.oracle_uq_optimize(o["rgbs"], o["sigmas"].reshape(-1), o["image"])
             obj = lambda p: Hh.oracle_uq_objective(o["rgbs"], o["sigmas"].reshape(-1), o["image"], p)   # noqa: E731
             np.testing.assert_allclose(o["mu"], mu_w, rtol=1e-2)
             assert abs(o["sigma"]) < 1e-2 * o["stats"]["std_d"] and abs(sigma_w) < 1e-2 * o["stats"]["std_d"]   # both far down the log(s^2) slope
-            assert abs(obj([o["mu"], o["sigma"]]) - obj([mu_w, sigma_w])) < 0.05 * max(1.0, abs(obj([mu_w, sigma_w])))
             # ... while the objective itself, at fixed parameters, is the same function on both sides
             from nerfsafetyvalidation_amd.uncertainty.quantification.gaussian_approximation_density_uncertainty import GaussianApproximationDensityUncertainty as UQ
             for prm in ([0.5, 1.0], [mu_w, 2 * abs(sigma_w)], [0.02, 0.3]):
