@@ -108,11 +108,14 @@ NGP_API int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_
 /* gridencoder.cu:415-446.  inputs f32 [B,D]; embeddings [sO,C] dtype; offsets_host: the
  * SAME int32[L+1] table as the device `offsets` tensor, in host memory (the level
  * geometry is evaluated on the host once per call); outputs [L,B,C] dtype;
- * dy_dx [B,L*D*C] dtype or NULL.  D in {2,3}, C in {1,2,4,8}. */
+ * dy_dx [B,L*D*C] dtype or NULL.  D in {2,3}, C in {1,2,4,8}.
+ * cell_tables (optional, may be NULL; fp16, D = 3, C = 2 only): the per-cell corner records of the first cell_levels levels of
+ * THIS table (ngp_build_cell_tables, below) -- a derived copy that turns eight 4-byte gathers per level into one 32-byte
+ * record read.  Results are bit-identical with and without it; the caller rebuilds it when the table changes. */
 NGP_API int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                             int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
-                            ngp_stream_t stream);
+                            const void* cell_tables, uint32_t cell_levels, ngp_stream_t stream);
 /* gridencoder.cu:448-478.  grad [L,B,C]; grad_embeddings [sO,C] (accumulated into, caller zero-fills; NULL with calc_grad_inputs set = frozen table, only grad_inputs is produced);
  * grad_inputs [B,D] dtype or NULL. */
 NGP_API int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,

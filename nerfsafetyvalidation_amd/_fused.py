@@ -25,10 +25,14 @@ def _versions(tensors):
 
 
 class FusedModel:
-    def __init__(self, net, emb16, sigma_blob, sigma_mm, color_blob, color_mm, watched):
+    def __init__(self, net, sigma_blob, sigma_mm, color_blob, color_mm, watched):
+        from .gridencoder.grid import derived_tables
         enc = net.encoder
         if enc.input_dim != 3 or enc.num_levels != 16 or enc.level_dim != 2:
             raise RuntimeError("fused renderer needs the 3-D, 16-level, 2-feature hash grid")
+        # fp16 copy of the table and, later, its per-cell records: shared with the grid_encode operator (one entry per parameter version)
+        self._tables = derived_tables(enc.embeddings)
+        emb16 = self._tables.emb16
         self.device = emb16.device
         self.emb16, self.sigma_blob, self.color_blob = emb16, sigma_blob, color_blob
         self.sigma_mm, self.color_mm = sigma_mm, color_mm
@@ -60,8 +64,8 @@ class FusedModel:
         if net.hidden_dim != 64 or net.hidden_dim_color != 64 or net.in_dim != 32 or net.in_dim_color != 32:
             raise RuntimeError("fused renderer needs 64-wide FFMLPs on 32-wide inputs")
         watched = [net.encoder.embeddings, net.sigma_net.weights, net.color_net.weights]
-        return cls(net, net.encoder.embeddings.detach().half().contiguous(), net.sigma_net.weights.detach().half().contiguous(),
-                   net.num_layers - 1, net.color_net.weights.detach().half().contiguous(), net.num_layers_color - 1, watched)
+        return cls(net, net.sigma_net.weights.detach().half().contiguous(), net.num_layers - 1,
+                   net.color_net.weights.detach().half().contiguous(), net.num_layers_color - 1, watched)
 
     @classmethod
     def from_linear_network(cls, net):
@@ -81,8 +85,7 @@ class FusedModel:
         if net.hidden_dim != 64 or net.hidden_dim_color != 64 or net.geo_feat_dim != 15:
             raise RuntimeError("fused renderer needs 64-wide MLPs and geo_feat_dim == 15")
         watched = [net.encoder.embeddings] + [l.weight for l in net.sigma_net] + [l.weight for l in net.color_net]
-        return cls(net, net.encoder.embeddings.detach().half().contiguous(), blob(net.sigma_net, 32), len(net.sigma_net) - 2,
-                   blob(net.color_net, 32), len(net.color_net) - 2, watched)
+        return cls(net, blob(net.sigma_net, 32), len(net.sigma_net) - 2, blob(net.color_net, 32), len(net.color_net) - 2, watched)
 
     def valid_for(self, net):
         return (_versions(self._watched) == self._snapshot and self.density_scale == float(net.density_scale)
@@ -119,26 +122,14 @@ class FusedModel:
             self._packed = packed
 
     def _ensure_cells(self):
-        """Expand the first twelve levels when the budget and a third of the free device memory allow."""
+        """Expand the first twelve levels when the budget and a third of the free device memory allow (gridencoder.grid.DerivedTables)."""
         self._ensure_packed()
         if self._cells_ready:
             return
-        with self._ctx_lock:
-            if self._cells_ready:
-                return
-            lib = _lib.lib()
-            m = self._struct(None)
-            free, _ = torch.cuda.mem_get_info(self.device)
-            budget = min(self.cell_table_gb * (1 << 30), free / 3)
-            for n in (12,):          # (the kernels are specialised for exactly twelve expanded levels)
-                nbytes = lib.ngp_cell_tables_bytes(C.byref(m), n)
-                if 0 < nbytes <= budget:
-                    cells = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-                    _lib.check(lib.ngp_build_cell_tables(C.byref(m), n, _lib.ptr(cells), _lib.stream()), "build_cell_tables")
-                    self._cells, self._cell_levels = cells, n
-                    break
-            torch.cuda.current_stream(self.device).synchronize()   # other streams may render with the derived copies next
-            self._cells_ready = True
+        if self.cell_table_gb > 0:
+            self._cells, self._cell_levels = self._tables.ensure_cells(self.offsets_host, self.S, self.H_base, self.gridtype, self.align_corners,
+                                                                       self.cell_table_gb)
+        self._cells_ready = True
 
     def network_forward(self, xyzs, dirs):
         """fused NeRFNetwork.forward: xyzs, dirs [M,3] f32 -> sigma [M] f32 (unscaled), rgb [M,3] f32 (fp16-rounded)"""

@@ -55,7 +55,7 @@ SIGNATURES = {
     "ngp_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
                        _u32, _vp],
     "ngp_composite_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "ngp_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int, _int, _vp],
+    "ngp_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int, _int, _vp, _u32, _vp],
     "ngp_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _u32, _int,
                                  _int, _vp, _sz, _vp],
     "ngp_grid_encode_backward_workspace": [_u32, _u32, _u32, _u32, _int],

@@ -170,6 +170,122 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
     }
 }
 
+// ---- the common shape (3-D, two fp16 features) with four levels per lane ---------------------------------------------------------
+// One lane owns a point for the level group q, q + 4, q + 8, q + 12 (q = 0..3: every group holds coarse and fine levels, the same
+// split the fused kernels use): the point is read once per four levels, 32 gathers are in flight per lane, and a wave writes 64
+// consecutive points of a level plane (256 contiguous bytes).  Workgroups of one group run on one pair of XCDs (hardware deals
+// consecutive workgroups round-robin over the 8 XCDs), so a hashed level is only ever read through two L2s.
+// With per-cell corner records (ngp_build_cell_tables; `cells` != NULL) the first `cell_levels` levels read one 32-byte record
+// (two 16-byte loads, one cache line) instead of eight 4-byte gathers from up to four lines.  The records hold copies of the
+// table entries and the arithmetic below is the reference's (c10::Half accumulation, corner order 0..7): bit-identical outputs.
+template <bool GRAD>
+__global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __restrict__ inputs, const _Float16* __restrict__ grid,
+                                                                 _Float16* __restrict__ outputs, uint32_t B, uint32_t L, GridLevels lv,
+                                                                 _Float16* __restrict__ dy_dx, uint32_t gridtype, bool align_corners,
+                                                                 const uint4* __restrict__ cells, uint32_t cell_levels, GridLevels cell_off) {
+    constexpr int D = 3, C = 2;
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, k = bid >> 3;
+    const uint32_t q = xcd >> 1;
+    const uint32_t b = (k * 2 + (xcd & 1u)) * kGridBlock + threadIdx.x;
+    if (b >= B) return;
+    float in[D];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        oob |= (in[d] < 0 || in[d] > 1);
+    }
+    using V = Vec<_Float16, C>;
+    if (oob) {      // :107-123
+        for (uint32_t level = q; level < L; level += 4) {
+            V z;
+            z.v[0] = (_Float16)0; z.v[1] = (_Float16)0;
+            *reinterpret_cast<V*>(outputs + ((size_t)level * B + b) * C) = z;
+            if (GRAD) {
+                _Float16* dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+                for (int i = 0; i < D * C; i++) dd[i] = (_Float16)0;
+            }
+        }
+        return;
+    }
+    uint32_t raw[4][8];
+    float fr[4][D];
+    const uint32_t* tab32 = reinterpret_cast<const uint32_t*>(grid);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t level = q + 4 * i;
+        if (level >= L) break;
+        const float scale = lv.scale[level];
+        uint32_t pg[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const float p = fmaf(in[d], scale, align_corners ? 0.0f : 0.5f);
+            pg[d] = (uint32_t)floorf(p);
+            fr[i][d] = p - (float)pg[d];
+        }
+        if (cells != nullptr && level < cell_levels) {
+            const uint32_t S = lv.resolution[level];
+            const uint4* r = cells + (size_t)(cell_off.offset[level] + pg[0] + S * (pg[1] + S * pg[2])) * 2;
+            const uint4 lo = r[0], hi = r[1];
+            raw[i][0] = lo.x; raw[i][1] = lo.y; raw[i][2] = lo.z; raw[i][3] = lo.w;
+            raw[i][4] = hi.x; raw[i][5] = hi.y; raw[i][6] = hi.z; raw[i][7] = hi.w;
+        } else {
+            const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level], resolution = lv.resolution[level];
+            const uint32_t* tab = tab32 + lv.offset[level];
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) {
+                const uint32_t pl[D] = {pg[0] + (idx & 1), pg[1] + ((idx >> 1) & 1), pg[2] + ((idx >> 2) & 1)};
+                raw[i][idx] = tab[grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl)];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t level = q + 4 * i;
+        if (level >= L) break;
+        V corner[8];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) corner[idx] = __builtin_bit_cast(V, raw[i][idx]);
+        V res;
+        res.v[0] = (_Float16)0; res.v[1] = (_Float16)0;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            float w = 1;
+#pragma unroll
+            for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? fr[i][d] : 1 - fr[i][d];
+            acc_mul(res.v[0], w, corner[idx].v[0]);
+            acc_mul(res.v[1], w, corner[idx].v[1]);
+        }
+        *reinterpret_cast<V*>(outputs + ((size_t)level * B + b) * C) = res;
+        if (GRAD) {     // :177-222
+            const float scale = lv.scale[level];
+            _Float16* dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+            for (int gd = 0; gd < D; gd++) {
+                _Float16 rg[C] = {(_Float16)0, (_Float16)0};
+#pragma unroll
+                for (int idx = 0; idx < 4; idx++) {
+                    float w = scale;
+                    int left = 0;
+#pragma unroll
+                    for (int nd = 0; nd < D - 1; nd++) {
+                        const int d = (nd >= gd) ? (nd + 1) : nd;
+                        const int bit = (idx >> nd) & 1;
+                        w *= bit ? fr[i][d] : 1 - fr[i][d];
+                        left |= bit << d;
+                    }
+                    const int right = left | (1 << gd);
+#pragma unroll
+                    for (int c = 0; c < C; c++) acc_mul(rg[c], w, (_Float16)(corner[right].v[c] - corner[left].v[c]));
+                }
+                dd[gd * C] = rg[0];
+                dd[gd * C + 1] = rg[1];
+            }
+        }
+    }
+}
+
 // :227-314 scatter of w * grad into the table gradient.
 //
 // MI355X: float atomics execute at the memory side (MI355X_MICROARCH.md "Global float atomics"): ~20 G scattered updates/s
@@ -486,6 +602,10 @@ __global__ void __launch_bounds__(256) k_grid_bwd_bin_reduce(const uint2* __rest
 // workspace of the binned scatter: the caller's (ngp_grid_encode_backward_workspace gives the size that lets every level of a
 // group go through the bins in one pass; with less, the levels are processed in smaller groups, with none they use atomics)
 constexpr size_t kBinWorkspaceMax = (size_t)4 << 30;    // levels are processed in groups that fit this
+static bool g4_off() {                                   // diagnostics (NGP_GRID_NO_G4 set): the one-lane-per-(point, level) kernel for every shape
+    static const bool off = getenv("NGP_GRID_NO_G4") != nullptr;
+    return off;
+}
 static bool bin_off() {                                  // diagnostics (NGP_GRID_NO_BINS set): atomics for every level
     static const bool off = getenv("NGP_GRID_NO_BINS") != nullptr;
     return off;
@@ -531,7 +651,10 @@ void fill_levels(GridLevels& lv, const int32_t* offsets_host, uint32_t L, float 
         lv.mul1[l] = mul[1];
         lv.mul2[l] = mul[2];
         lv.hashed[l] = (gridtype == 0 && stride > size) ? 1 : 0;
-        const bool dense = !lv.hashed[l] && stride <= size;  // every dim consumed and the full index range fits
+        // every dim consumed and the full index range fits -- except with align_corners, where an input of exactly 1 indexes grid
+        // point `resolution` (one past the last, gridencoder.cu:137-139 with pos = x * scale): the reference wraps it with its
+        // unconditional `% hashmap_size` (:71), so those levels keep the modulo
+        const bool dense = !lv.hashed[l] && stride <= size && !align_corners;
         lv.mode[l] = dense ? 0 : ((size & (size - 1)) == 0 ? 1 : 2);
     }
     lv.offset[L] = (uint32_t)offsets_host[L];
@@ -639,7 +762,8 @@ extern "C" {
 
 int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs, uint32_t B,
                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
-                            uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream) {
+                            uint32_t gridtype, int align_corners, int dtype, const void* cell_tables, uint32_t cell_levels,
+                            ngp_stream_t stream) {
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
     NGP_REQUIRE(D == 2 || D == 3, "GridEncoding: D must be 2 or 3 on this build (got %u)", D);
@@ -652,7 +776,27 @@ int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const i
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("grid_encode_forward", s, B);
     const bool g = calc_grad_inputs != 0, ac = align_corners != 0;
-    if (dtype == NGP_F32) {
+    if (dtype == NGP_F16 && D == 3 && C == 2 && !g4_off()) {
+        // the common shape: four levels per lane, optionally through the per-cell corner records (same values, same arithmetic)
+        GridLevels cell_off = {};
+        const uint4* cells = nullptr;
+        if (cell_tables && cell_levels) {
+            NGP_REQUIRE(cell_levels <= L && ((uintptr_t)cell_tables & 15) == 0, "grid_encode_forward: bad cell tables (levels %u of %u, or misaligned)",
+                        cell_levels, L);
+            uint64_t total = 0;
+            for (uint32_t l = 0; l < cell_levels; l++) {
+                cell_off.offset[l] = (uint32_t)total;
+                total += (uint64_t)lv.resolution[l] * lv.resolution[l] * lv.resolution[l];
+            }
+            NGP_REQUIRE(total < (1ull << 32), "grid_encode_forward: the cell tables of %u levels exceed 2^32 records", cell_levels);
+            cells = reinterpret_cast<const uint4*>(cell_tables);
+        }
+        const uint32_t nblocks = 8 * div_up(div_up(B, kGridBlock), 2);
+        if (g) k_grid_forward_g4<true><<<nblocks, kGridBlock, 0, s>>>(inputs, (const _Float16*)embeddings, (_Float16*)outputs, B, L, lv, (_Float16*)dy_dx,
+                                                                       gridtype, ac, cells, cell_levels, cell_off);
+        else k_grid_forward_g4<false><<<nblocks, kGridBlock, 0, s>>>(inputs, (const _Float16*)embeddings, (_Float16*)outputs, B, L, lv, nullptr, gridtype, ac,
+                                                                     cells, cell_levels, cell_off);
+    } else if (dtype == NGP_F32) {
         NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, s)
     } else {
         NGP_DISPATCH_DC(launch_forward, _Float16, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, s)

@@ -4,6 +4,11 @@ GridEncoder keeps the reference's constructor, parameters (`embeddings` [n, leve
 U(-1e-4, 1e-4)), `offsets` buffer, `output_dim` and forward(inputs, bound=1) contract.
 The native call is ngp_grid_encode_forward/backward (include/ngp_hip.h).
 """
+import ctypes as C
+import os
+import threading
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -13,6 +18,74 @@ from torch.amp import custom_bwd, custom_fwd
 from .. import _lib
 
 _gridtype_to_id = {"hash": 0, "tiled": 1}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Derived copies of a table, kept per PARAMETER and per version of it: the fp16 copy autocast asks for on every forward
+# (grid.py:38-39 converts all 12.6 M entries per call) and, once the table has been seen unchanged a second time outside autograd
+# (or an eighth time at all) -- i.e. it is being evaluated, not trained -- its per-cell corner records (ngp_build_cell_tables: 32 bytes per grid cell of the
+# first twelve levels, 38 GB for the bound-2 table, within a budget).  The operator and the fused kernels (_fused.FusedModel)
+# share one entry.  Both are value copies: results do not depend on them.
+# ---------------------------------------------------------------------------------------------------------------------------
+class DerivedTables:
+    def __init__(self, param):
+        self.key = (param.data_ptr(), param._version, param.device)
+        self.emb16 = param.detach().to(torch.half).contiguous()
+        self.seen = 1
+        self.cells, self.cell_levels, self.cells_tried = None, 0, False
+        self.lock = threading.Lock()
+
+    def ensure_cells(self, offsets_host, S, H_base, gridtype, align_corners, budget_gb=None):
+        """build the per-cell records of the first twelve levels if they fit the budget (GB; default NGP_CELL_TABLE_GB or 48, and a
+        third of the free device memory).  Idempotent; returns (cells or None, levels)."""
+        if self.cells_tried:
+            return self.cells, self.cell_levels
+        with self.lock:
+            if self.cells_tried:
+                return self.cells, self.cell_levels
+            if budget_gb is None:
+                budget_gb = float(os.environ.get("NGP_CELL_TABLE_GB", 48))
+            lib = _lib.lib()
+            m = _lib.ModelStruct()
+            m.embeddings = _lib.ptr(self.emb16)
+            m.offsets_host = C.cast(offsets_host, C.c_void_p)
+            m.L, m.S, m.H_base, m.gridtype, m.align_corners = 16, S, H_base, gridtype, int(align_corners)
+            free, _ = torch.cuda.mem_get_info(self.emb16.device)
+            nbytes = lib.ngp_cell_tables_bytes(C.byref(m), 12)
+            if 0 < nbytes <= min(budget_gb * (1 << 30), free / 3):
+                cells = torch.empty(nbytes, dtype=torch.uint8, device=self.emb16.device)
+                _lib.check(lib.ngp_build_cell_tables(C.byref(m), 12, _lib.ptr(cells), _lib.stream()), "build_cell_tables")
+                torch.cuda.current_stream(self.emb16.device).synchronize()   # other streams may read it next
+                self.cells, self.cell_levels = cells, 12
+            self.cells_tried = True
+        return self.cells, self.cell_levels
+
+
+_DERIVED = {}                      # id(param) -> (weak reference to the parameter, DerivedTables); entries die with their parameter
+_DERIVED_LOCK = threading.Lock()   # (a WeakKeyDictionary would compare tensors with ==, which is elementwise)
+
+
+def _forget(pid):
+    with _DERIVED_LOCK:
+        _DERIVED.pop(pid, None)
+
+
+def derived_tables(param):
+    """the DerivedTables of this version of `param` (created, or re-created when the parameter changed since)"""
+    key, pid = (param.data_ptr(), param._version, param.device), id(param)
+    with _DERIVED_LOCK:
+        slot = _DERIVED.get(pid)
+        if slot is not None and slot[0]() is param and slot[1].key == key:
+            slot[1].seen += 1
+            return slot[1]
+        ent = DerivedTables(param)
+        _DERIVED[pid] = (weakref.ref(param, lambda _r, pid=pid: _forget(pid)), ent)
+        return ent
+
+
+def invalidate_derived(param):
+    """forget the derived copies (after writing the parameter through `.data` or a raw pointer, which bumps no version)"""
+    _forget(id(param))
 
 
 class _grid_encode(Function):
@@ -30,9 +103,18 @@ class _grid_encode(Function):
         S = float(np.log2(per_level_scale))  # crosses the ABI as a C float, as in the reference (grid.py:33)
         H = base_resolution
 
-        # manual autocast: half embeddings only when C is even (grid.py:36-39)
+        # manual autocast: half embeddings only when C is even (grid.py:36-39).  The fp16 copy is kept per version of the parameter
+        # (the reference converts the whole table on every call); a table that is evaluated repeatedly without changing also gets
+        # its per-cell corner records, which the kernel reads instead of gathering (same values: bit-identical outputs).
+        cells, cell_levels = None, 0
         if torch.is_autocast_enabled("cuda") and C % 2 == 0:
-            embeddings = embeddings.to(torch.half)
+            if embeddings.dtype == torch.float32 and isinstance(embeddings, nn.Parameter):
+                ent = derived_tables(embeddings)
+                embeddings = ent.emb16
+                if ((ent.seen >= 2 and not torch.is_grad_enabled()) or ent.seen >= 8) and D == 3 and C == 2 and L == 16:
+                    cells, cell_levels = ent.ensure_cells(_lib.host_i32(offsets), S, H, gridtype, align_corners)
+            else:
+                embeddings = embeddings.to(torch.half)
         embeddings = embeddings.contiguous()
 
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
@@ -41,7 +123,7 @@ class _grid_encode(Function):
         lib = _lib.lib()
         _lib.check(lib.ngp_grid_encode_forward(_lib.ptr(inputs), _lib.ptr(embeddings), _lib.host_i32(offsets), _lib.ptr(outputs),
                                                B, D, C, L, S, H, int(calc_grad_inputs), _lib.ptr(dy_dx), gridtype,
-                                               int(align_corners), _lib.dtype_code(embeddings), _lib.stream()),
+                                               int(align_corners), _lib.dtype_code(embeddings), _lib.ptr(cells), cell_levels, _lib.stream()),
                    "grid_encode_forward")
 
         outputs = outputs.permute(1, 0, 2).reshape(B, L * C)  # [L,B,C] -> [B, L*C] (grid.py:52)

@@ -101,8 +101,13 @@ class NeRFRenderer(nn.Module):
         through `.data` (torch_ema's copy_to / restore in the reference Trainer, nerf/utils.py:846-850,932-933) or raw pointers do
         not: call this after such a write.  Entering training mode and load_state_dict call it themselves."""
         from .. import _fused
+        from ..gridencoder.grid import invalidate_derived
         with _fused.CACHE_LOCK:
             self._fused_cache = None
+        for name in ("encoder", "encoder_bg"):          # the grid encoders' fp16 copies / per-cell records follow the same rule
+            enc = getattr(self, name, None)
+            if enc is not None and hasattr(enc, "embeddings"):
+                invalidate_derived(enc.embeddings)
 
     def train(self, mode=True):
         if mode:

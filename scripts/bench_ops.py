@@ -22,7 +22,6 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2097152
 mode = sys.argv[2] if len(sys.argv) > 2 else "random"
 enc = GridEncoder(desired_resolution=4096).to(dev)
 enc.embeddings.data.uniform_(-0.5, 0.5)
-emb16 = enc.embeddings.detach().half()
 if mode == "random":
     x = torch.rand(B, 3, device=dev)
 else:  # coherent: consecutive samples along rays (what the renderer produces)
@@ -31,14 +30,20 @@ else:  # coherent: consecutive samples along rays (what the renderer produces)
     x = (o + d * torch.linspace(0, 0.45, T, device=dev).view(1, T, 1)).clamp(0, 1).reshape(-1, 3).contiguous()
 out = torch.empty(16, B, 2, dtype=torch.half, device=dev)
 offs = _lib.host_i32(enc.offsets); S = float(np.log2(enc.per_level_scale))
-def grid():
-    _lib.check(lib.ngp_grid_encode_forward(x.data_ptr(), emb16.data_ptr(), offs, out.data_ptr(), B, 3, 2, 16, S, 16, 0, None, 0, 0, 1,
-                                           torch.cuda.current_stream().cuda_stream))
-ms, _ = timed("grid_encode_forward", grid)
+from nerfsafetyvalidation_amd.gridencoder.grid import derived_tables
+ent = derived_tables(enc.embeddings)
+cells, cell_levels = ent.ensure_cells(offs, S, 16, 0, False)
 bytes_alg = B * 588
-print(json.dumps({"op": "grid_encode_forward f16 L16 F2", "B": B, "inputs": mode, "ms": round(ms, 4), "points_per_s": round(B / ms * 1e3),
-                  "roofline": {"bound": "hbm", "achieved": round(bytes_alg / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(bytes_alg / ms / 1e6 / 8000.0, 4)}}))
+for tag, ct, cl in (("plain gathers", None, 0), ("per-cell records for levels 0-11", cells, cell_levels)):
+    if tag != "plain gathers" and ct is None:
+        continue
+    def grid():
+        _lib.check(lib.ngp_grid_encode_forward(x.data_ptr(), ent.emb16.data_ptr(), offs, out.data_ptr(), B, 3, 2, 16, S, 16, 0, None, 0, 0, 1,
+                                               ct.data_ptr() if ct is not None else None, cl, torch.cuda.current_stream().cuda_stream))
+    ms, _ = timed("grid_encode_forward", grid)
+    print(json.dumps({"op": "grid_encode_forward f16 L16 F2", "table": tag, "B": B, "inputs": mode, "ms": round(ms, 4), "points_per_s": round(B / ms * 1e3),
+                      "roofline": {"bound": "hbm", "achieved": round(bytes_alg / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(bytes_alg / ms / 1e6 / 8000.0, 4)}}))
 # ffmlp forward + backward (training path): sigma-net shape 32 -> 64 -> 64 -> 16
 from nerfsafetyvalidation_amd.ffmlp import FFMLP
 Bf = min(B, 1 << 20)

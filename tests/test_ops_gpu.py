@@ -514,3 +514,75 @@ def test_grid_encode_full_size_properties(device, dtype):
     got = out[torch.from_numpy(sel).to(device)].cpu().numpy()
     bits = np.uint32 if dtype == np.float32 else np.uint16
     assert np.array_equal(got.view(bits), want.view(bits))
+
+
+@pytest.mark.parametrize("gridtype,align", [(0, False), (1, False), (0, True)])
+def test_grid_encode_forward_through_cell_records_bit_exact(device, gridtype, align):
+    """ngp_grid_encode_forward with the per-cell corner records of the first twelve levels (ngp_build_cell_tables): outputs and
+    dy_dx are the oracle's bit for bit -- the records are copies of table entries, the accumulation order and the c10::Half
+    rounding are the reference's -- and equal the call without records."""
+    import ctypes as C
+    from nerfsafetyvalidation_amd import _lib
+    rng = np.random.default_rng(17)
+    L = 16
+    offsets, pls = Hh.grid_offsets(input_dim=3, num_levels=L, log2_hashmap_size=19, desired_resolution=384, align_corners=align)
+    S = float(np.log2(pls))
+    emb = rng.uniform(-0.5, 0.5, (offsets[-1], 2)).astype(np.float16)
+    B = 5000
+    x = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    x[0], x[1], x[4] = 0.0, 1.0, 0.5
+    x[2, 0], x[3, 1] = 1.0000001, -1e-7
+    x[5:500] = (x[5:6] + np.linspace(0, 0.2, 495)[:, None] * np.array([0.3, 0.5, 0.8], np.float32)).astype(np.float32)   # a ray: coherent samples
+    want, want_dydx = Hh.oracle_grid_encode(x, emb, offsets, pls, calc_grad=True, gridtype=gridtype, align_corners=align)
+    lib = _lib.lib()
+    emb_t, x_t = _t(emb, device), _t(x, device)
+    host = (C.c_int32 * (L + 1))(*[int(v) for v in offsets])
+    m = _lib.ModelStruct()
+    m.embeddings, m.offsets_host = _lib.ptr(emb_t), C.cast(host, C.c_void_p)
+    m.L, m.S, m.H_base, m.gridtype, m.align_corners = L, S, 16, gridtype, int(align)
+    nbytes = lib.ngp_cell_tables_bytes(C.byref(m), 12)
+    assert 0 < nbytes < (1 << 31)
+    cells = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _lib.check(lib.ngp_build_cell_tables(C.byref(m), 12, _lib.ptr(cells), _lib.stream()), "build_cell_tables")
+    results = []
+    for ct, cl in ((None, 0), (cells, 12)):
+        out = torch.full((L, B, 2), 7.0, dtype=torch.float16, device=device)
+        dydx = torch.full((B, L * 6), 7.0, dtype=torch.float16, device=device)
+        _lib.check(lib.ngp_grid_encode_forward(_lib.ptr(x_t), _lib.ptr(emb_t), host, _lib.ptr(out), B, 3, 2, L, S, 16, 1, _lib.ptr(dydx), gridtype, int(align),
+                                               _lib.NGP_F16, _lib.ptr(ct), cl, _lib.stream()), "grid_encode_forward")
+        got = out.permute(1, 0, 2).reshape(B, L * 2).cpu().numpy()
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (ct is not None, int((got.view(np.uint16) != want.view(np.uint16)).sum()))
+        assert np.array_equal(dydx.cpu().numpy().view(np.uint16), want_dydx.view(np.uint16))
+        results.append((out, dydx))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    with pytest.raises(RuntimeError):      # records of more levels than the table has
+        _lib.check(lib.ngp_grid_encode_forward(_lib.ptr(x_t), _lib.ptr(emb_t), host, _lib.ptr(results[0][0]), B, 3, 2, L, S, 16, 0, None, gridtype, int(align),
+                                               _lib.NGP_F16, _lib.ptr(cells), 20, _lib.stream()), "grid_encode_forward")
+
+
+def test_grid_encoder_module_keeps_derived_tables_per_parameter_version(device):
+    """GridEncoder under autocast: the fp16 copy of the table is made once per parameter version, the per-cell records appear when
+    the same version is evaluated again outside autograd, an in-place update drops both, and the outputs never change."""
+    from nerfsafetyvalidation_amd.gridencoder import GridEncoder
+    from nerfsafetyvalidation_amd.gridencoder.grid import derived_tables
+    enc = GridEncoder(desired_resolution=256).to(device)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-0.5, 0.5)
+    x = torch.rand(4000, 3, device=device) * 2 - 1
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = enc(x, bound=1.0)
+        ent = derived_tables(enc.embeddings)
+        assert ent.cells is None
+        b = enc(x, bound=1.0)                       # second evaluation of the same version: records are built and used
+        ent2 = derived_tables(enc.embeddings)
+        assert ent2 is ent and ent.cells is not None and ent.cell_levels == 12
+        c = enc(x, bound=1.0)
+    assert torch.equal(a, b) and torch.equal(a, c) and a.dtype == torch.float16
+    with torch.no_grad():
+        enc.embeddings.mul_(0.5)                    # bumps the version: a new entry, no records yet
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        d = enc(x, bound=1.0)
+    ent3 = derived_tables(enc.embeddings)
+    assert ent3 is not ent and ent3.cells is None and not torch.equal(a, d)
+    want = (enc.embeddings.detach().half())
+    assert torch.equal(ent3.emb16, want)
