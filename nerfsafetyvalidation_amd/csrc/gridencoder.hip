@@ -170,24 +170,31 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
     }
 }
 
-// ---- the common shape (3-D, two fp16 features) with four levels per lane ---------------------------------------------------------
-// One lane owns a point for the level group q, q + 4, q + 8, q + 12 (q = 0..3: every group holds coarse and fine levels, the same
-// split the fused kernels use): the point is read once per four levels, 32 gathers are in flight per lane, and a wave writes 64
-// consecutive points of a level plane (256 contiguous bytes).  Workgroups of one group run on one pair of XCDs (hardware deals
-// consecutive workgroups round-robin over the 8 XCDs), so a hashed level is only ever read through two L2s.
+// ---- the common shape (3-D, two fp16 features) with several levels per lane ---------------------------------------------------------
+// One lane owns a point for a small set of levels: the point is read once for the set, 16 (32) gathers are in flight per lane, and a
+// wave writes 64 consecutive points of a level plane (256 contiguous bytes).
 // With per-cell corner records (ngp_build_cell_tables; `cells` != NULL) the first `cell_levels` levels read one 32-byte record
 // (two 16-byte loads, one cache line) instead of eight 4-byte gathers from up to four lines.  The records hold copies of the
 // table entries and the arithmetic below is the reference's (c10::Half accumulation, corner order 0..7): bit-identical outputs.
-template <bool GRAD>
+// PAIR variant (tables without records): two levels per lane, l and L - 1 - l with l = the workgroup's XCD -- the level-to-XCD
+// assignment of k_grid_forward (a hashed level only ever goes through ONE 4 MiB L2), half the point reads, 16 gathers in flight.
+template <bool GRAD, bool PAIR>
 __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __restrict__ inputs, const _Float16* __restrict__ grid,
                                                                  _Float16* __restrict__ outputs, uint32_t B, uint32_t L, GridLevels lv,
                                                                  _Float16* __restrict__ dy_dx, uint32_t gridtype, bool align_corners,
                                                                  const uint4* __restrict__ cells, uint32_t cell_levels, GridLevels cell_off) {
     constexpr int D = 3, C = 2;
+    constexpr int NL = PAIR ? 2 : 4;                 // levels per lane
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, k = bid >> 3;
-    const uint32_t q = xcd >> 1;
-    const uint32_t b = (k * 2 + (xcd & 1u)) * kGridBlock + threadIdx.x;
-    if (b >= B) return;
+    // PAIR: levels (j, L - 1 - j) for j = xcd, xcd + 8, ... < L / 2, all points through every XCD; else group q = xcd / 2 of 4 levels
+    const uint32_t LP = PAIR ? (L + 15u) / 16u : 1u;
+    const uint32_t q = PAIR ? xcd + 8u * (k % LP) : xcd >> 1;
+    const uint32_t b = (PAIR ? k / LP : k * 2 + (xcd & 1u)) * kGridBlock + threadIdx.x;
+    if (b >= B || (PAIR && q >= (L + 1) / 2)) return;
+    uint32_t levels[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) levels[i] = PAIR ? (i == 0 ? q : L - 1 - q) : q + 4 * i;
+    const uint32_t n_levels = PAIR ? (levels[0] == levels[1] ? 1u : 2u) : 4u;
     float in[D];
     bool oob = false;
 #pragma unroll
@@ -197,7 +204,9 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
     }
     using V = Vec<_Float16, C>;
     if (oob) {      // :107-123
-        for (uint32_t level = q; level < L; level += 4) {
+        for (uint32_t i = 0; i < n_levels; i++) {
+            const uint32_t level = levels[i];
+            if (level >= L) break;
             V z;
             z.v[0] = (_Float16)0; z.v[1] = (_Float16)0;
             *reinterpret_cast<V*>(outputs + ((size_t)level * B + b) * C) = z;
@@ -209,13 +218,13 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
         }
         return;
     }
-    uint32_t raw[4][8];
-    float fr[4][D];
+    uint32_t raw[NL][8];
+    float fr[NL][D];
     const uint32_t* tab32 = reinterpret_cast<const uint32_t*>(grid);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t level = q + 4 * i;
-        if (level >= L) break;
+    for (int i = 0; i < NL; i++) {
+        const uint32_t level = levels[i];
+        if (level >= L || (uint32_t)i >= n_levels) break;
         const float scale = lv.scale[level];
         uint32_t pg[D];
 #pragma unroll
@@ -241,9 +250,9 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t level = q + 4 * i;
-        if (level >= L) break;
+    for (int i = 0; i < NL; i++) {
+        const uint32_t level = levels[i];
+        if (level >= L || (uint32_t)i >= n_levels) break;
         V corner[8];
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) corner[idx] = __builtin_bit_cast(V, raw[i][idx]);
@@ -791,11 +800,14 @@ int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const i
             NGP_REQUIRE(total < (1ull << 32), "grid_encode_forward: the cell tables of %u levels exceed 2^32 records", cell_levels);
             cells = reinterpret_cast<const uint4*>(cell_tables);
         }
-        const uint32_t nblocks = 8 * div_up(div_up(B, kGridBlock), 2);
-        if (g) k_grid_forward_g4<true><<<nblocks, kGridBlock, 0, s>>>(inputs, (const _Float16*)embeddings, (_Float16*)outputs, B, L, lv, (_Float16*)dy_dx,
-                                                                       gridtype, ac, cells, cell_levels, cell_off);
-        else k_grid_forward_g4<false><<<nblocks, kGridBlock, 0, s>>>(inputs, (const _Float16*)embeddings, (_Float16*)outputs, B, L, lv, nullptr, gridtype, ac,
-                                                                     cells, cell_levels, cell_off);
+        const _Float16* e16 = (const _Float16*)embeddings;
+        _Float16 *o16 = (_Float16*)outputs, *d16 = (_Float16*)dy_dx;
+        // Level pairs (l, L - 1 - l) pinned to XCD l % 8, with or without records.  Measured on 2 M points (profiles/r02_bench_ops.jsonl):
+        // the alternative -- groups of four levels on XCD pairs, one gathered hashed level per group when twelve levels come from
+        // records -- is 12-20 % slower in every case (more distinct hashed levels per L2).
+        const uint32_t nblocks = 8 * ((L + 15) / 16) * div_up(B, kGridBlock);
+        if (g) k_grid_forward_g4<true, true><<<nblocks, kGridBlock, 0, s>>>(inputs, e16, o16, B, L, lv, d16, gridtype, ac, cells, cells ? cell_levels : 0, cell_off);
+        else k_grid_forward_g4<false, true><<<nblocks, kGridBlock, 0, s>>>(inputs, e16, o16, B, L, lv, nullptr, gridtype, ac, cells, cells ? cell_levels : 0, cell_off);
     } else if (dtype == NGP_F32) {
         NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, s)
     } else {
