@@ -294,6 +294,20 @@ NGP_API int ngp_render_uniform(const ngp_model* model, const float* rays_o, cons
                        float* image, float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs,
                        ngp_stream_t stream);
 
+/* Vector-Jacobian product of ngp_render_uniform with respect to the RAYS with the map (table, weights) frozen: what
+ * nav/estimator_helpers.py:191-225 differentiates (pose gradients through get_rays -> render -> run, <= 1024 pixels x 512 samples).
+ * One launch, nothing saved by the forward call: grad_image [N,3] (of the image BEFORE the background mix), grad_depth /
+ * grad_weights_sum / grad_aggregated_density [N] (each may be NULL = zero) -> grad_rays_o, grad_rays_d [N,3] (overwritten).
+ * packed_weights_bwd: ngp_pack_weights_bwd(model, buf) -- the transposed weights as MFMA fragments
+ * (ngp_packed_weights_bwd_bytes() bytes, 16-byte aligned), packed once per parameter version.  T <= 1024 and the LDS budget
+ * (160 KB: both weight sets + 12 B per sample and resident wave) must hold, else NGP_EINVAL: T <= 512 for the reference's networks. */
+NGP_API size_t ngp_packed_weights_bwd_bytes(void);
+NGP_API int ngp_pack_weights_bwd(const ngp_model* model, void* out, ngp_stream_t stream);
+NGP_API int ngp_render_uniform_backward(const ngp_model* model, const void* packed_weights_bwd, const float* rays_o, const float* rays_d,
+                                const float* nears, const float* fars, uint32_t N, uint32_t T, const float* lin, const float* grad_image,
+                                const float* grad_depth, const float* grad_weights_sum, const float* grad_aggregated_density,
+                                float* grad_rays_o, float* grad_rays_d, ngp_stream_t stream);
+
 /* ---------------- sample bookkeeping of NeRFRenderer.run (nerf/renderer.py:12-46, 125-258), operator form ---------------- */
 
 /* :148-160.  z_vals [N,T] = nears + (fars - nears) * lin[t] (lin = the T values of torch.linspace(0, 1, T), device memory), plus
@@ -377,6 +391,9 @@ NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
  * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
+/* Diagnostics of ngp_render_uniform_backward: float [N][T][4] device buffer receiving, per sample, sigma, the transmittance before
+ * it, dL/dw and dL/dsigma (NULL = off; process-wide, single-threaded use). */
+NGP_API int ngp_debug_set_grad_dump(float* device_buf);
 NGP_API int ngp_render_ctx_set_debug(ngp_render_ctx* ctx, int enable, int flags, unsigned long long* stamps, uint32_t* sample_hash);
 
 /* ---------------- per-kernel device timing (bench.py roofline leg) ---------------- */

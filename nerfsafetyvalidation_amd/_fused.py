@@ -20,6 +20,27 @@ from . import _lib
 CACHE_LOCK = threading.Lock()   # serialises the (re)building of a network's FusedModel snapshot
 
 
+class RunUniform(torch.autograd.Function):
+    """NeRFRenderer.run without upsampling as ONE launch forward (ngp_render_uniform) and ONE launch backward
+    (ngp_render_uniform_backward) -- differentiable in the rays, the map frozen: the pose gradients of the state estimator."""
+
+    @staticmethod
+    def forward(ctx, fm, rays_o, rays_d, nears, fars, num_steps, dump_begin):
+        rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
+        ws, depth, image, agg, sigmas, rgbs = fm.render_uniform(rays_o, rays_d, nears, fars, num_steps, dump_begin)
+        ctx.fm, ctx.num_steps = fm, num_steps
+        ctx.save_for_backward(rays_o, rays_d, nears, fars)
+        ctx.mark_non_differentiable(sigmas, rgbs)
+        return ws, depth, image, agg, sigmas, rgbs
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_image, g_agg, _g_sigmas, _g_rgbs):
+        rays_o, rays_d, nears, fars = ctx.saved_tensors
+        zeros = g_image if g_image is not None else torch.zeros(rays_o.shape[0], 3, device=rays_o.device)
+        go, gd = ctx.fm.render_uniform_backward(rays_o, rays_d, nears, fars, ctx.num_steps, zeros, g_depth, g_ws, g_agg)
+        return None, go, gd, None, None, None, None
+
+
 def _versions(tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors)
 
@@ -56,6 +77,7 @@ class FusedModel:
         self._cell_levels = 0
         self._cells_ready = False
         self._packed = None      # the two weight blobs as MFMA fragments (ngp_pack_weights), packed with the cell tables
+        self._packed_bwd = None  # ... and transposed, for the fused backward of `run` (ngp_pack_weights_bwd), on first use
         self.debug = None        # (flags, stamps tensor or None, sample-hash tensor or None): diagnostics state of THIS model's contexts
 
     # ---- construction from the two backbones ---------------------------------------------------------
@@ -239,6 +261,36 @@ class FusedModel:
                                           N, T, _lib.ptr(lin), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
                                           dump_begin, _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.stream()), "render_uniform")
         return out[0], out[1], out[2], out[3], sigmas, rgbs
+
+    def render_uniform_backward(self, rays_o, rays_d, nears, fars, num_steps, g_image, g_depth=None, g_ws=None, g_agg=None):
+        """vector-Jacobian product of render_uniform w.r.t. the rays, map frozen (ngp_render_uniform_backward): upstream gradients of
+        image (before the background mix) [N,3], depth / weights_sum / aggregated_density [N] (None = zero) -> grad_rays_o, grad_rays_d"""
+        self._ensure_cells()
+        lib = _lib.lib()
+        if self._packed_bwd is None:
+            with self._ctx_lock:
+                if self._packed_bwd is None:
+                    buf = torch.empty(lib.ngp_packed_weights_bwd_bytes(), dtype=torch.uint8, device=self.device)
+                    _lib.check(lib.ngp_pack_weights_bwd(C.byref(self._struct(None)), _lib.ptr(buf), _lib.stream()), "pack_weights_bwd")
+                    torch.cuda.current_stream(self.device).synchronize()
+                    self._packed_bwd = buf
+        N, T, dev = rays_o.shape[0], int(num_steps), rays_o.device
+        lin = torch.linspace(0.0, 1.0, T, device=dev)
+        f32 = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
+        go = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        gd = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        m = self._struct(None)
+        _lib.check(lib.ngp_render_uniform_backward(C.byref(m), _lib.ptr(self._packed_bwd), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()),
+                                                   _lib.ptr(fars.contiguous()), N, T, _lib.ptr(lin), _lib.ptr(f32(g_image)), _lib.ptr(f32(g_depth)),
+                                                   _lib.ptr(f32(g_ws)), _lib.ptr(f32(g_agg)), _lib.ptr(go), _lib.ptr(gd), _lib.stream()),
+                   "render_uniform_backward")
+        return go, gd
+
+    def uniform_backward_fits(self, num_steps):
+        """LDS budget of the fused backward (160 KB): both weight sets + 12 bytes per sample for each of its 8 resident rays"""
+        weights = 2 * ((2048 + self.sigma_mm * 4096 + 1024) + (2048 + self.color_mm * 4096 + 1024))
+        weights += 2 * ((4096 + self.sigma_mm * 4096) + (4096 + self.color_mm * 4096))
+        return num_steps <= 1024 and weights + 1024 + 8 * 12 * num_steps <= 160 * 1024
 
     def __del__(self):
         try:

@@ -83,6 +83,9 @@ SIGNATURES = {
                         C.POINTER(C.c_float), C.POINTER(RenderStats), _int, _vp],
     "ngp_network_forward": [C.POINTER(ModelStruct), _vp, _vp, _u32, _vp, _vp, _vp],
     "ngp_network_density": [C.POINTER(ModelStruct), _vp, _u32, _vp, _vp],
+    "ngp_packed_weights_bwd_bytes": [],
+    "ngp_pack_weights_bwd": [C.POINTER(ModelStruct), _vp, _vp],
+    "ngp_render_uniform_backward": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ngp_uniform_samples": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp],
     "ngp_uniform_samples_backward": [_vp, _vp, _vp, _vp, _u32, _u32, C.POINTER(C.c_float), _vp, _vp, _vp],
     "ngp_transmittance_weights": [_vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp],
@@ -99,11 +102,12 @@ SIGNATURES = {
     "ngp_debug_set_sample_hash": [_vp],
     "ngp_debug_disable_march_queue": [_int],
     "ngp_render_ctx_set_debug": [_vp, _int, _int, _vp, _vp],
+    "ngp_debug_set_grad_dump": [_vp],
     "ngp_prof_enable": [_int],
     "ngp_prof_reset": [],
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
-_RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
+_RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_packed_weights_bwd_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
              "ngp_ffmlp_backward_workspace": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
 
 _lib = None

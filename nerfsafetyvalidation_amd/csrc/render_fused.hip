@@ -594,7 +594,10 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
                     rgbs[row * 3] = cr; rgbs[row * 3 + 1] = cg; rgbs[row * 3 + 2] = cb;
                 }
             }
-            carry *= __shfl(incl, 15, 16);
+            // (lanes 16..63 evaluate other rows of the sigma net in `sigma`: only quarter 0's transmittance is the ray's.  The exit
+            //  below must be taken by the WHOLE wave at once -- a quarter that left early would stop gathering its levels -- hence
+            //  the broadcast of lane 0's value)
+            carry = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(carry * __shfl(incl, 15, 16))));
             // everything further down the ray is weighted by <= carry: below fp32 resolution of the O(1) sums
             if (!dump && carry < 1e-10f) break;
         }
@@ -607,6 +610,433 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
             weights_sum[ray] = a_ws; depth[ray] = a_dep; aggregated_density[ray] = a_agg;
             image[(size_t)ray * 3] = a_r; image[(size_t)ray * 3 + 1] = a_g; image[(size_t)ray * 3 + 2] = a_b;
         }
+    }
+}
+
+// ==========================================================================================
+// Differentiable `run`: the vector-Jacobian product of k_render_uniform with respect to the RAYS, map frozen.
+// What nav/estimator_helpers.py:191-225 (measurement_fn) differentiates -- <= 1024 chosen pixels x 512 samples, 100 Adam steps per
+// simulator step -- is d(image, depth) / d(rays_o, rays_d) through sampling -> hash grid -> sigma net -> SH -> colour net ->
+// compositing, with table and weights constant.  The reference (and this package's operator path) gets it from autograd over
+// ~60 kernels and [N, T, *] saved tensors; here it is ONE launch, one wave per ray, nothing saved by the forward pass:
+//
+//   pass 1  forward over the ray's tiles (as k_render_uniform): per sample sigma, transmittance T_i and the upstream gradient
+//           of its weight, g_i = dL/dw_i = G_img . rgb_i [w_i > 1e-4] + G_depth rel_i + G_ws + G_agg sigma_i, into LDS;
+//   scan    reverse scan over the samples: dL/dalpha_j = g_j T_j - (sum_{i>j} g_i w_i) / p_j  ->  dL/dsigma_j, in place;
+//   pass 2  per tile, recompute the network keeping every layer's activations in registers and walk it backwards with the
+//           TRANSPOSED weights (packed as MFMA A fragments by k_pack_weights_bwd: dH_prev^T = W^T dH^T, the same accumulator ->
+//           B-fragment trick as forward, so gradients never leave registers either): colour net -> (SH', geo) -> sigma net ->
+//           hash-grid input derivative from the corners already gathered -> clip -> (grad o, grad d), reduced over the ray.
+//
+// Rounding points follow the operator path: fp16 activations and activation gradients, fp32 MFMA accumulation, fp32 everywhere
+// outside the MLPs.
+// ==========================================================================================
+__host__ __device__ inline uint32_t bwd_halfs(uint32_t mm) { return 2048 + mm * 4096 + 2048; }
+
+// Transposed fragments.  Per net: [out layer: ob 4][lane][8] | [hidden layers, LAST first: ob 4][s 2][lane][8] | [in layer: ob 2][s 2][lane][8]
+//   out layer   : A[row = unit 16 ob + c][k(q, j)] = j < 4 ? W_out[4q + j][unit] : 0      (B fragment = the lane's own 4 output gradients)
+//   hidden layer: A[row = unit 16 ob + c of the layer BELOW][k = perm_hidden(q, j, s)] = W[perm_hidden(q, j, s)][that unit]
+//   in layer    : accumulator row 4 q' + r of block ob is the gradient of input feature phi(q', 4 ob + r), phi = perm_grid / perm_color:
+//                 A[row i][k = perm_hidden(q, j, s)] = W_in[perm_hidden(q, j, s)][phi(i >> 2, 4 ob + (i & 3))]
+__global__ void k_pack_weights_bwd(const _Float16* __restrict__ sig, uint32_t sig_mm, const _Float16* __restrict__ col, uint32_t col_mm,
+                                   _Float16* __restrict__ packed) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_sig = bwd_halfs(sig_mm), n_col = bwd_halfs(col_mm);
+    if (e >= n_sig + n_col) return;
+    const bool is_col = e >= n_sig;
+    const uint32_t r = is_col ? e - n_sig : e;
+    const uint32_t mm = is_col ? col_mm : sig_mm;
+    const _Float16* src = is_col ? col : sig;
+    const uint32_t j = r & 7, lane = (r >> 3) & 63, c = lane & 15, q = lane >> 4;
+    const uint32_t w_hid = 2048, w_out = 2048 + mm * 4096;           // offsets inside the FFMLP-layout source blob
+    _Float16 v;
+    if (r < 2048) {                                                   // out layer [ob][lane][8]
+        const uint32_t ob = r >> 9;
+        v = j < 4 ? src[w_out + (4 * q + j) * 64 + 16 * ob + c] : (_Float16)0;
+    } else if (r < 2048 + mm * 4096) {                                // hidden layers, last first
+        const uint32_t rr = r - 2048, slot = rr >> 12, in = rr & 4095;
+        const uint32_t layer = mm - 1 - slot;
+        const uint32_t ob = in >> 10, st = (in >> 9) & 1;
+        v = src[w_hid + layer * 4096 + perm_hidden(q, j, st) * 64 + 16 * ob + c];
+    } else {                                                          // in layer [ob 2][s 2][lane][8]
+        const uint32_t in = r - 2048 - mm * 4096, ob = in >> 10, st = (in >> 9) & 1;
+        const uint32_t i = c, qq = i >> 2, jj = 4 * ob + (i & 3);
+        const uint32_t feat = is_col ? perm_color(qq, jj) : perm_grid(qq, jj);
+        v = src[perm_hidden(q, j, st) * 32 + feat];
+    }
+    packed[e] = v;
+}
+
+__device__ __forceinline__ void mlp_out_bwd(const half8* Wt, uint32_t lane, half8 g, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wt[ob * 64 + lane], g, (f32x4){0, 0, 0, 0}, 0, 0, 0);
+}
+__device__ __forceinline__ void mlp_hidden_bwd(const half8* Wt, uint32_t lane, const half8 (&g)[2], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) {
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wt[(ob * 2 + 0) * 64 + lane], g[0], (f32x4){0, 0, 0, 0}, 0, 0, 0);
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wt[(ob * 2 + 1) * 64 + lane], g[1], acc[ob], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void mlp_in_bwd(const half8* Wt, uint32_t lane, const half8 (&g)[2], f32x4 (&acc)[2]) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++) {
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wt[(ob * 2 + 0) * 64 + lane], g[0], (f32x4){0, 0, 0, 0}, 0, 0, 0);
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wt[(ob * 2 + 1) * 64 + lane], g[1], acc[ob], 0, 0, 0);
+    }
+}
+// gradient through ReLU at the layer whose (post-activation) forward values are h: pass where h > 0; fp16 like the operator's buffers
+__device__ __forceinline__ void relu_mask_pack(const f32x4 (&acc)[4], const half8 (&h)[2], half8 (&g)[2]) {
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const _Float16 v = (_Float16)acc[2 * st + (jj >> 2)][jj & 3];
+            g[st][jj] = h[st][jj] > (_Float16)0 ? v : (_Float16)0;
+        }
+}
+
+// d SH_k / d (x, y, z) for k = 4q .. 4q + 3 contracted with g[4] (the closed forms of sh4_quarter differentiated)
+__device__ __forceinline__ void sh4_quarter_vjp(uint32_t q, float x, float y, float z, const float (&g)[4], float (&o)[3]) {
+    const float a = 0.48860251190291987f, b = 1.0925484305920792f, c2 = 2.0f * 0.94617469575755997f, e = 0.54627421529603959f,
+                f = 0.59004358992664352f, gg = 2.8906114426405538f, h = 0.45704579946446572f, k = 0.3731763325901154f, m = 1.4453057213202769f;
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    if (q == 0) {
+        o[0] = -a * g[3]; o[1] = -a * g[1]; o[2] = a * g[2];
+    } else if (q == 1) {
+        o[0] = b * y * g[0] - b * z * g[3];
+        o[1] = b * x * g[0] - b * z * g[1];
+        o[2] = -b * y * g[1] + c2 * z * g[2] - b * x * g[3];
+    } else if (q == 2) {
+        o[0] = 2 * e * x * g[0] - 6 * f * x * y * g[1] + gg * y * z * g[2];
+        o[1] = -2 * e * y * g[0] + f * (-3 * x2 + 3 * y2) * g[1] + gg * x * z * g[2] + h * (1 - 5 * z2) * g[3];
+        o[2] = gg * x * y * g[2] - 10 * h * y * z * g[3];
+    } else {
+        o[0] = h * (1 - 5 * z2) * g[1] + 2 * m * x * z * g[2] + f * (-3 * x2 + 3 * y2) * g[3];
+        o[1] = -2 * m * y * z * g[2] + 6 * f * x * y * g[3];
+        o[2] = k * (15 * z2 - 3) * g[0] - 10 * h * x * z * g[1] + m * (x2 - y2) * g[2];
+    }
+}
+
+struct GradArgs {
+    const float *rays_o, *rays_d, *nears, *fars, *lin;
+    const float *g_image, *g_depth, *g_ws, *g_agg;      // upstream gradients of the four per-ray outputs (g_depth / g_ws / g_agg may be NULL)
+    float *grad_o, *grad_d;
+    const _Float16* packed_bwd;
+    uint32_t N, T;
+    float aabb_lo, aabb_hi;
+    float* dump;    // diagnostics (ngp_debug_set_grad_dump): [N][T][4] = sigma, transmittance, dL/dw, dL/dsigma per sample; NULL = off
+};
+
+constexpr int kGradWaves = 8;
+constexpr uint32_t kGradMaxT = 1024;
+
+template <int MODE>
+__global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetArgs na, GridLevels lv, GradArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
+    const size_t wb_bytes = (size_t)(bwd_halfs(na.sig_mm) + bwd_halfs(na.col_mm)) * 2;
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    _Float16* Wb = reinterpret_cast<_Float16*>(smem + w_bytes);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes + wb_bytes);
+    float* store = reinterpret_cast<float*>(smem + w_bytes + wb_bytes + sizeof(LevelTab));
+    {   // transposed fragments next to the forward ones
+        const uint4* src = reinterpret_cast<const uint4*>(ga.packed_bwd);
+        uint4* dst = reinterpret_cast<uint4*>(Wb);
+        for (uint32_t i = threadIdx.x; i < wb_bytes / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const uint32_t T = ga.T;
+    float* s_sig = store + (size_t)wid * 3 * T;      // pass 1: sigma (raw);  after the scan: dL/dsigma
+    float* s_g = s_sig + T;                          // pass 1: dL/dw;        after the scan: w [w > 1e-4] (the scale of dL/drgb)
+    float* s_T = s_g + T;                            // transmittance before the sample
+    const half8* Ws = reinterpret_cast<const half8*>(Wlds);
+    const half8* Wc = reinterpret_cast<const half8*>(Wlds + sig_halfs(na.sig_mm));
+    const half8* Bs = reinterpret_cast<const half8*>(Wb);
+    const half8* Bc = reinterpret_cast<const half8*>(Wb + bwd_halfs(na.sig_mm));
+    const float half_off = na.align_corners ? 0.0f : 0.5f;
+
+    for (uint32_t ray = blockIdx.x * kGradWaves + wid; ray < ga.N; ray += gridDim.x * kGradWaves) {
+        const float ox = ga.rays_o[(size_t)ray * 3], oy = ga.rays_o[(size_t)ray * 3 + 1], oz = ga.rays_o[(size_t)ray * 3 + 2];
+        const float dx = ga.rays_d[(size_t)ray * 3], dy = ga.rays_d[(size_t)ray * 3 + 1], dz = ga.rays_d[(size_t)ray * 3 + 2];
+        const float near = ga.nears[ray], far = ga.fars[ray], span = far - near;
+        const float sample_dist = span * (1.0f / (float)T);
+        const float Gi0 = ga.g_image[(size_t)ray * 3], Gi1 = ga.g_image[(size_t)ray * 3 + 1], Gi2 = ga.g_image[(size_t)ray * 3 + 2];
+        const float Gd = ga.g_depth ? ga.g_depth[ray] : 0.0f, Gw = ga.g_ws ? ga.g_ws[ray] : 0.0f, Ga = ga.g_agg ? ga.g_agg[ray] : 0.0f;
+        // ---------------- pass 1: forward, exactly k_render_uniform's arithmetic ----------------
+        float carry = 1.0f;
+        uint32_t t_end = T;                                           // samples >= t_end carry no weight (transmittance below 1e-10)
+        for (uint32_t i0 = 0; i0 < T; i0 += 16) {
+            const uint32_t idx = i0 + c;
+            const bool valid = idx < T;
+            const uint32_t ii = valid ? idx : T - 1;
+            const float zv = near + span * ga.lin[ii];
+            const float x = clampf(ox + dx * zv, ga.aabb_lo, ga.aabb_hi), y = clampf(oy + dy * zv, ga.aabb_lo, ga.aabb_hi),
+                        z = clampf(oz + dz * zv, ga.aabb_lo, ga.aabb_hi);
+            float sigma;
+            _Float16 s16[4];
+            net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+            const float z_next = (ii + 1 < T) ? near + span * ga.lin[ii + 1] : 0.0f;
+            const float delta = (ii + 1 < T) ? z_next - zv : sample_dist;
+            const float alpha = valid ? 1.0f - expf(((-delta) * na.density_scale) * sigma) : 0.0f;
+            const float p = (1.0f - alpha) + 1e-15f;
+            float incl = p;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float o = __shfl_up(incl, off, 16);
+                if (c >= (uint32_t)off) incl *= o;
+            }
+            const float excl = __shfl_up(incl, 1, 16);
+            const float Tr = carry * (c == 0 ? 1.0f : excl);
+            const float w = alpha * Tr;
+            const bool masked = valid && w > 1e-4f;
+            float cr = 0, cg = 0, cb = 0;
+            if (__ballot(masked && lane < 16) != 0ull) {
+                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                if (!masked) { cr = 0; cg = 0; cb = 0; }
+            }
+            if (lane < 16 && valid) {
+                const float qz = (zv - near) / span;
+                const float rel = qz != qz ? 0.0f : fminf(1.0f, fmaxf(0.0f, qz));
+                s_sig[idx] = sigma;
+                s_T[idx] = Tr;
+                s_g[idx] = fmaf(Gi0, cr, fmaf(Gi1, cg, Gi2 * cb)) + Gd * rel + Gw + Ga * sigma;
+            }
+            carry = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(carry * __shfl(incl, 15, 16))));   // quarter 0's value, for the whole wave
+            if (carry < 1e-10f) { t_end = (i0 + 16 < T) ? i0 + 16 : T; break; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- reverse scan: dL/dsigma_j and the colour scale w_j [w_j > 1e-4] ----------------
+        float suffix = 0.0f;
+        for (uint32_t c0 = ((t_end + 63) / 64) * 64; c0 > 0; c0 -= 64) {
+            const uint32_t t = c0 - 64 + lane;
+            const bool on = t < t_end;
+            const uint32_t tt = on ? t : t_end - 1;
+            const float zv = near + span * ga.lin[tt];
+            const float delta = (tt + 1 < T) ? (near + span * ga.lin[tt + 1]) - zv : sample_dist;
+            const float sg = s_sig[tt], Tr = s_T[tt];
+            const float e = expf(((-delta) * na.density_scale) * sg);
+            const float alpha = 1.0f - e, p = (1.0f - alpha) + 1e-15f, w = alpha * Tr;
+            const float g = on ? s_g[tt] : 0.0f;
+            const float gw = on ? g * w : 0.0f;
+            float inc = gw;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_down(inc, off, 64);
+                if (lane + (uint32_t)off < 64) inc += o;
+            }
+            const float later = suffix + (inc - gw);
+            suffix += __shfl(inc, 0, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (on) {
+                const float dsg = (g * Tr - later / p) * ((delta * na.density_scale) * e) + Ga * w;
+                if (ga.dump) {
+                    float* o4 = ga.dump + ((size_t)ray * T + t) * 4;
+                    o4[0] = sg; o4[1] = Tr; o4[2] = g; o4[3] = dsg;
+                }
+                s_sig[t] = dsg;
+                s_g[t] = w > 1e-4f ? w : 0.0f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- pass 2: network backward per tile ----------------
+        float a_o[3] = {0, 0, 0}, a_d[3] = {0, 0, 0};
+        for (uint32_t i0 = 0; i0 < t_end; i0 += 16) {
+            const uint32_t idx = i0 + c;
+            const bool valid = idx < t_end;
+            const uint32_t ii = valid ? idx : t_end - 1;
+            const float zv = near + span * ga.lin[ii];
+            const float ux = ox + dx * zv, uy = oy + dy * zv, uz = oz + dz * zv;          // before the clip (for its derivative)
+            const float x = clampf(ux, ga.aabb_lo, ga.aabb_hi), y = clampf(uy, ga.aabb_lo, ga.aabb_hi), z = clampf(uz, ga.aabb_lo, ga.aabb_hi);
+            // ---- forward recompute, keeping corners and activations
+            float u[3];
+            bool oob;
+            encoder_unit(na, x, y, z, u, oob);
+            uint32_t raw[4][8];
+            float fr[4][3], scl[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t level = q + 4 * i;
+                const float scale = lt->scale[level];
+                scl[i] = scale;
+                uint32_t g3[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float pz = fmaf(u[d], scale, half_off);
+                    g3[d] = (uint32_t)floorf(pz);
+                    fr[i][d] = pz - (float)g3[d];
+                }
+                if (MODE == 2 && i < 3) {
+                    const uint32_t S = lt->cell_res[level];
+                    const uint4* rec = na.cells + (size_t)(lt->cell_off[level] + g3[0] + S * (g3[1] + S * g3[2])) * 2;
+                    const uint4 lo = rec[0], hi = rec[1];
+                    raw[i][0] = lo.x; raw[i][1] = lo.y; raw[i][2] = lo.z; raw[i][3] = lo.w;
+                    raw[i][4] = hi.x; raw[i][5] = hi.y; raw[i][6] = hi.z; raw[i][7] = hi.w;
+                    continue;
+                }
+                const uint32_t* tab = na.table + lt->offset[level];
+                const uint32_t a1 = lt->a1[level], a2 = lt->a2[level], mask = lt->mask[level], fl = lt->flags[level];
+                const bool hashed = (fl & 1u) != 0;
+                const uint32_t t1[2] = {g3[1] * a1, g3[1] * a1 + a1}, t2[2] = {g3[2] * a2, g3[2] * a2 + a2};
+#pragma unroll
+                for (int k8 = 0; k8 < 8; k8++) {
+                    const uint32_t px = g3[0] + (k8 & 1), ty = t1[(k8 >> 1) & 1], tz = t2[(k8 >> 2) & 1];
+                    uint32_t en = hashed ? (px ^ ty ^ tz) : (px + ty + tz);
+                    en &= mask;
+                    if (MODE == 1) { if (fl & 2u) en %= lt->size[level]; }
+                    raw[i][k8] = tab[en];
+                }
+            }
+            half8 feat;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                _Float16 f0, f1;
+                corners_to_feature(fr[i], raw[i], oob, f0, f1);
+                feat[2 * i] = f0; feat[2 * i + 1] = f1;
+            }
+            half8 hs[3][2], hs_last[2];                            // sigma net: post-activations of the input layer and of each hidden layer
+            mlp_in(Ws, lane, feat, hs[0]);                         // (indices stay compile-time constants: register arrays)
+            hs_last[0] = hs[0][0]; hs_last[1] = hs[0][1];
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if ((uint32_t)k < na.sig_mm) {
+                    mlp_hidden(Ws + 256 + k * 512, lane, hs_last);
+                    hs[k + 1][0] = hs_last[0]; hs[k + 1][1] = hs_last[1];
+                }
+            const f32x4 so = mlp_out(Ws + 256 + na.sig_mm * 512, lane, hs_last);
+            _Float16 s16[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) s16[r] = (_Float16)so[r];
+            const float wscale = valid ? s_g[ii] : 0.0f;            // w [w > 1e-4]: zero when the reference does not evaluate the colour
+            const float dsig = valid ? s_sig[ii] : 0.0f;
+            f32x4 gso = {0, 0, 0, 0};                               // dL/d(sigma-net outputs 4q .. 4q+3) of sample c
+            float gdir[3] = {0, 0, 0};
+            if (__ballot(wscale != 0.0f && lane < 16) != 0ull) {
+                // ---- colour net forward with kept activations
+                float sh[4];
+                sh4_quarter(q, dx, dy, dz, sh);
+                half8 cin;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { cin[r] = (_Float16)sh[r]; cin[4 + r] = s16[r]; }
+                if (q == 0) cin[4] = (_Float16)0;
+                half8 hc[4][2], hc_last[2];
+                mlp_in(Wc, lane, cin, hc[0]);
+                hc_last[0] = hc[0][0]; hc_last[1] = hc[0][1];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if ((uint32_t)k < na.col_mm) {
+                        mlp_hidden(Wc + 256 + k * 512, lane, hc_last);
+                        hc[k + 1][0] = hc_last[0]; hc[k + 1][1] = hc_last[1];
+                    }
+                const f32x4 co = mlp_out(Wc + 256 + na.col_mm * 512, lane, hc_last);
+                // ---- backward: sigmoid (on the fp16-rounded value, as torch.sigmoid's backward does), out layer, hidden, in
+                const float wsc = __shfl(wscale, c, 64);             // lanes 0..15 hold the per-sample values: broadcast to the sample's 4 lanes
+                half8 gco = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (q == 0) {
+                    const float G[3] = {Gi0, Gi1, Gi2};
+#pragma unroll
+                    for (int k3 = 0; k3 < 3; k3++) {
+                        const float yv = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[k3])));
+                        gco[k3] = (_Float16)(G[k3] * wsc * (yv * (1.0f - yv)));
+                    }
+                }
+                f32x4 acc[4];
+                half8 gc[2];
+                mlp_out_bwd(Bc, lane, gco, acc);
+                relu_mask_pack(acc, hc_last, gc);
+#pragma unroll
+                for (int l = 2; l >= 0; l--)                        // through hidden matmul l (input activations hc[l]), last first
+                    if ((uint32_t)l < na.col_mm) {
+                        mlp_hidden_bwd(Bc + 256 + (na.col_mm - 1 - l) * 512, lane, gc, acc);
+                        relu_mask_pack(acc, hc[l], gc);
+                    }
+                f32x4 gin[2];
+                mlp_in_bwd(Bc + 256 + na.col_mm * 512, lane, gc, gin);
+                // accumulator (ob, r) = gradient of colour input perm_color(q, 4 ob + r): ob 0 -> SH 4q + r, ob 1 -> sigma-net output 4q + r
+                const float gsh[4] = {(float)(_Float16)gin[0][0], (float)(_Float16)gin[0][1], (float)(_Float16)gin[0][2], (float)(_Float16)gin[0][3]};
+                sh4_quarter_vjp(q, dx, dy, dz, gsh, gdir);
+#pragma unroll
+                for (int r = 0; r < 4; r++) gso[r] = (float)(_Float16)gin[1][r];
+                if (q == 0) gso[0] = 0.0f;                          // that slot was the zero pad, not sigma
+            }
+            // ---- sigma: trunc_exp backward (activation.py:12-17) on output 0
+            {
+                const float ds = __shfl(dsig, c, 64);
+                if (q == 0) gso[0] = ds * expf(fminf(15.0f, fmaxf(-15.0f, (float)s16[0])));
+            }
+            half8 gs_out = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; r++) gs_out[r] = (_Float16)gso[r];
+            f32x4 acc[4];
+            half8 gsn[2];
+            mlp_out_bwd(Bs, lane, gs_out, acc);
+            relu_mask_pack(acc, hs_last, gsn);
+#pragma unroll
+            for (int l = 1; l >= 0; l--)
+                if ((uint32_t)l < na.sig_mm) {
+                    mlp_hidden_bwd(Bs + 256 + (na.sig_mm - 1 - l) * 512, lane, gsn, acc);
+                    relu_mask_pack(acc, hs[l], gsn);
+                }
+            f32x4 gfe[2];
+            mlp_in_bwd(Bs + 256 + na.sig_mm * 512, lane, gsn, gfe);
+            // accumulator (ob, r) = gradient of feature perm_grid(q, 4 ob + r) = level q + 4 (2 ob + (r >> 1)), channel r & 1
+            float gx[3] = {0, 0, 0};
+            if (!oob) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float g0 = (float)(_Float16)gfe[i >> 1][2 * (i & 1)], g1 = (float)(_Float16)gfe[i >> 1][2 * (i & 1) + 1];
+#pragma unroll
+                    for (int gd = 0; gd < 3; gd++) {              // gridencoder.cu:177-222: d feature / d u_gd = scale * sum_4 w (right - left)
+                        float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; k4++) {
+                            float w = scl[i];
+                            int left = 0;
+#pragma unroll
+                            for (int nd = 0; nd < 2; nd++) {
+                                const int d = (nd >= gd) ? (nd + 1) : nd;
+                                const int bit = (k4 >> nd) & 1;
+                                w *= bit ? fr[i][d] : 1 - fr[i][d];
+                                left |= bit << d;
+                            }
+                            const int right = left | (1 << gd);
+                            const uint32_t rl = raw[i][left], rr = raw[i][right];
+                            d0 = fmaf(w, (float)__builtin_bit_cast(_Float16, (uint16_t)(rr & 0xffffu)) - (float)__builtin_bit_cast(_Float16, (uint16_t)(rl & 0xffffu)), d0);
+                            d1 = fmaf(w, (float)__builtin_bit_cast(_Float16, (uint16_t)(rr >> 16)) - (float)__builtin_bit_cast(_Float16, (uint16_t)(rl >> 16)), d1);
+                        }
+                        gx[gd] = fmaf(g0, d0, fmaf(g1, d1, gx[gd]));
+                    }
+                }
+            }
+            // reduce the four level groups of a sample, then x = clip(o + d z): (x + bound) / (2 bound) upstream
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                gx[d] += __shfl_xor(gx[d], 16, 64);
+                gx[d] += __shfl_xor(gx[d], 32, 64);
+                gdir[d] += __shfl_xor(gdir[d], 16, 64);
+                gdir[d] += __shfl_xor(gdir[d], 32, 64);
+            }
+            if (lane < 16 && valid) {
+                const float uu[3] = {ux, uy, uz};
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float a = uu[d] > ga.aabb_lo ? 1.0f : (uu[d] == ga.aabb_lo ? 0.5f : 0.0f);
+                    const float v = fmaxf(uu[d], ga.aabb_lo);
+                    const float b = v < ga.aabb_hi ? 1.0f : (v == ga.aabb_hi ? 0.5f : 0.0f);
+                    const float gxd = gx[d] * na.inv_two_bound * (a * b);
+                    a_o[d] += gxd;
+                    a_d[d] = fmaf(gxd, zv, a_d[d]) + gdir[d];       // the direction also enters through SH (dirs = rays_d per sample)
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { a_o[d] += __shfl_xor(a_o[d], off, 16); a_d[d] += __shfl_xor(a_d[d], off, 16); }
+            if (lane == 0) { ga.grad_o[(size_t)ray * 3 + d] = a_o[d]; ga.grad_d[(size_t)ray * 3 + d] = a_d[d]; }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1364,6 +1794,7 @@ struct DebugState {
 };
 static std::mutex g_debug_mu;
 static DebugState g_debug_default;
+static float* g_grad_dump = nullptr;     // ngp_debug_set_grad_dump
 static DebugState debug_snapshot(const ngp_render_ctx* ctx) {
     if (ctx && ctx->has_debug) {
         DebugState d;
@@ -1751,6 +2182,11 @@ int ngp_debug_disable_march_queue(int off) {
     return NGP_OK;
 }
 
+int ngp_debug_set_grad_dump(float* device_buf) {
+    g_grad_dump = device_buf;
+    return NGP_OK;
+}
+
 int ngp_render_ctx_set_debug(ngp_render_ctx* ctx, int enable, int flags, unsigned long long* stamps, uint32_t* sample_hash) {
     NGP_REQUIRE(ctx, "render_ctx_set_debug: null context");
     ctx->has_debug = enable != 0;
@@ -1806,6 +2242,48 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
         k_render_uniform<0><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
                                                      dump_begin, sigmas, rgbs, -model->bound, model->bound);
     return check_launch("render_uniform");
+}
+
+size_t ngp_packed_weights_bwd_bytes(void) { return (size_t)(bwd_halfs(2) + bwd_halfs(3)) * 2; }
+
+int ngp_pack_weights_bwd(const ngp_model* model, void* out, ngp_stream_t stream) {
+    NGP_REQUIRE(model && model->sigma_weights && model->color_weights && out, "pack_weights_bwd: null pointer");
+    NGP_REQUIRE(model->sigma_hidden_mm <= 2 && model->color_hidden_mm <= 3, "pack_weights_bwd: at most 2 / 3 hidden matmuls (got %u / %u)",
+                model->sigma_hidden_mm, model->color_hidden_mm);
+    NGP_REQUIRE(((uintptr_t)out & 15) == 0, "pack_weights_bwd: the buffer must be 16-byte aligned");
+    const uint32_t n = bwd_halfs(model->sigma_hidden_mm) + bwd_halfs(model->color_hidden_mm);
+    k_pack_weights_bwd<<<div_up(n, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)model->sigma_weights, model->sigma_hidden_mm,
+                                                                        (const _Float16*)model->color_weights, model->color_hidden_mm, (_Float16*)out);
+    return check_launch("pack_weights_bwd");
+}
+
+int ngp_render_uniform_backward(const ngp_model* model, const void* packed_weights_bwd, const float* rays_o, const float* rays_d, const float* nears,
+                                const float* fars, uint32_t N, uint32_t T, const float* lin, const float* grad_image, const float* grad_depth,
+                                const float* grad_weights_sum, const float* grad_aggregated_density, float* grad_rays_o, float* grad_rays_d,
+                                ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && nears && fars && lin && grad_image && grad_rays_o && grad_rays_d, "render_uniform_backward: null pointer");
+    NGP_REQUIRE(model && model->packed_weights && packed_weights_bwd, "render_uniform_backward: packed weights missing (ngp_pack_weights / ngp_pack_weights_bwd)");
+    NGP_REQUIRE(T >= 1 && T <= kGradMaxT, "render_uniform_backward: 1 <= num_steps <= %u (got %u)", kGradMaxT, T);
+    hipStream_t s = (hipStream_t)stream;
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
+    if (rc) return rc;
+    GradArgs ga = {rays_o, rays_d, nears, fars, lin, grad_image, grad_depth, grad_weights_sum, grad_aggregated_density, grad_rays_o, grad_rays_d,
+                   (const _Float16*)packed_weights_bwd, N, T, -model->bound, model->bound, g_grad_dump};
+    const size_t lds = weights_bytes(na) + (size_t)(bwd_halfs(na.sig_mm) + bwd_halfs(na.col_mm)) * 2 + sizeof(LevelTab) + (size_t)kGradWaves * 3 * T * 4;
+    NGP_REQUIRE(lds <= 160 * 1024, "render_uniform_backward: LDS budget exceeded (%zu bytes: at most %u samples per ray with this network)", lds, T);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<0>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<1>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<2>), 160 * 1024);
+    uint32_t blocks = div_up(N, kGradWaves);
+    if (blocks > 512) blocks = 512;
+    ProfScope prof("render_uniform_backward", s, (double)N * T);
+    if (needs_generic(lv)) k_render_uniform_bwd<1><<<blocks, kGradWaves * 64, lds, s>>>(na, lv, ga);
+    else if (na.cells) k_render_uniform_bwd<2><<<blocks, kGradWaves * 64, lds, s>>>(na, lv, ga);
+    else k_render_uniform_bwd<0><<<blocks, kGradWaves * 64, lds, s>>>(na, lv, ga);
+    return check_launch("render_uniform_backward");
 }
 
 int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, float* sigmas, ngp_stream_t stream) {

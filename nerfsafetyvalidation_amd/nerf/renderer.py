@@ -338,19 +338,25 @@ class NeRFRenderer(nn.Module):
 
     def _render_staged_fused(self, fm, rays_o, rays_d, max_ray_batch, num_steps=128, bg_color=None, **kwargs):
         """staged render through `run` for the whole frame in ONE fused launch (ngp_render_uniform); same result dict as the chunk
-        loop below, including the last-chunk-only rgbs / sigmas (F8)."""
+        loop below, including the last-chunk-only rgbs / sigmas (F8).  Differentiable in the rays (one more launch,
+        ngp_render_uniform_backward): the network is treated as frozen here -- the caller checks that."""
+        from .._fused import RunUniform
         B, N = rays_o.shape[:2]
         aabb = self.aabb_train if self.training else self.aabb_infer
         depth, image, agg = [], [], []
         for b in range(B):
             o, d = rays_o[b].contiguous().view(-1, 3).float(), rays_d[b].contiguous().view(-1, 3).float()
-            nears, fars = raymarching.near_far_from_aabb(o, d, aabb, self.min_near)
+            with torch.no_grad():
+                nears, fars = raymarching.near_far_from_aabb(o, d, aabb, self.min_near)
             last_begin = ((N - 1) // max_ray_batch) * max_ray_batch          # first ray of the chunk the reference loop ends with
-            ws, dep, img, ag, sigmas, rgbs = fm.render_uniform(o, d, nears, fars, num_steps, last_begin)
+            ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin)
             img = img + (1 - ws).unsqueeze(-1) * (1 if bg_color is None else bg_color)
             depth.append(dep), image.append(img), agg.append(ag)
         return {"depth": torch.stack(depth, 0), "image": torch.stack(image, 0), "rgbs": rgbs, "sigmas": sigmas,
                 "aggregated_density": torch.stack(agg, 0)}
+
+    def _map_is_frozen(self):
+        return not any(p.requires_grad for p in self.parameters())
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """rays_o, rays_d [B,N,3] -> result dict of run / run_cuda.  `staged` (uniform-sample path only) renders max_ray_batch rays
@@ -358,11 +364,14 @@ class NeRFRenderer(nn.Module):
         the reference's loop overwrites them, and uncertain.py:80-88 consumes exactly those)."""
         if self.cuda_ray or not staged:
             return (self.run_cuda if self.cuda_ray else self.run)(rays_o, rays_d, **kwargs)
-        if self.fused and not torch.is_grad_enabled() and self.bg_radius <= 0 and kwargs.get("upsample_steps", 128) == 0 \
-                and not kwargs.get("perturb", False):
-            fm = self.fused_model()
-            if fm is not None and self._aabb_is_cube():
-                return self._render_staged_fused(fm, rays_o, rays_d, max_ray_batch, **kwargs)
+        if self.fused and self.bg_radius <= 0 and kwargs.get("upsample_steps", 128) == 0 and not kwargs.get("perturb", False):
+            # one fused launch for the frame.  Under autograd only when nothing but the rays can ask for a gradient (frozen map: the
+            # state estimator's pose fit) -- parameters that require a gradient get it through the operators below
+            if not torch.is_grad_enabled() or self._map_is_frozen():
+                wants_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)
+                fm = self.fused_model()
+                if fm is not None and self._aabb_is_cube() and (not wants_grad or fm.uniform_backward_fits(int(kwargs.get("num_steps", 128)))):
+                    return self._render_staged_fused(fm, rays_o, rays_d, max_ray_batch, **kwargs)
         n_cams, n_rays = rays_o.shape[:2]
         per_camera = []
         for cam in range(n_cams):
