@@ -391,6 +391,13 @@ NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
  * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
+/* Diagnostics: the 32 hash-grid features of xyzs [M,3] (positions in [-bound, bound]) exactly as the fused kernels' gather forms them
+ * -> features [M,32] fp16 in the operator's order (2 * level + channel).  operator_rounding = 0: the fused kernels' arithmetic (fp32
+ * accumulation of the 8 corners, one rounding); 1: the grid_encode operator's (c10::Half product and running sum,
+ * gridencoder.cu:169-172) through the same gather -- bit-identical to ngp_grid_encode_forward, which is how the default's
+ * deviation from the reference arithmetic is measured (tests/test_render_gpu.py). */
+NGP_API int ngp_debug_fused_features(const ngp_model* model, const float* xyzs, uint32_t M, int operator_rounding, uint16_t* features,
+                             ngp_stream_t stream);
 /* Diagnostics of ngp_render_uniform_backward: float [N][T][4] device buffer receiving, per sample, sigma, the transmittance before
  * it, dL/dw and dL/dsigma (NULL = off; process-wide, single-threaded use). */
 NGP_API int ngp_debug_set_grad_dump(float* device_buf);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "ngp_debug_disable_march_queue": [_int],
     "ngp_render_ctx_set_debug": [_vp, _int, _int, _vp, _vp],
     "ngp_debug_set_grad_dump": [_vp],
+    "ngp_debug_fused_features": [C.POINTER(ModelStruct), _vp, _u32, _int, _vp, _vp],
     "ngp_prof_enable": [_int],
     "ngp_prof_reset": [],
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],

@@ -346,19 +346,28 @@ __device__ __forceinline__ void hashed_gather(const NetArgs& na, const LevelTab&
     }
 }
 
+// HALF_ACC (diagnostics only, ngp_debug_fused_features): the grid_encode operator's arithmetic instead -- every product rounded to
+// fp16, fp16 running sum (c10::Half, gridencoder.cu:169-172) -- to measure what the default's single rounding changes.
+template <bool HALF_ACC = false>
 __device__ __forceinline__ void corners_to_feature(const float (&fr)[3], const uint32_t (&raw)[8], bool oob, _Float16& f0, _Float16& f1) {
     float a0 = 0.0f, a1 = 0.0f;
+    _Float16 h0 = (_Float16)0, h1 = (_Float16)0;
 #pragma unroll
     for (int idx = 0; idx < 8; idx++) {
         const float wx = (idx & 1) ? fr[0] : 1 - fr[0];
         const float wy = (idx & 2) ? fr[1] : 1 - fr[1];
         const float wz = (idx & 4) ? fr[2] : 1 - fr[2];
         const float w = (wx * wy) * wz;
-        a0 = fma_mix_lo(w, raw[idx], a0);
-        a1 = fma_mix_hi(w, raw[idx], a1);
+        if (HALF_ACC) {
+            h0 = h0 + mul_round_f16(w, __builtin_bit_cast(_Float16, (uint16_t)(raw[idx] & 0xffffu)));
+            h1 = h1 + mul_round_f16(w, __builtin_bit_cast(_Float16, (uint16_t)(raw[idx] >> 16)));
+        } else {
+            a0 = fma_mix_lo(w, raw[idx], a0);
+            a1 = fma_mix_hi(w, raw[idx], a1);
+        }
     }
-    f0 = oob ? (_Float16)0 : (_Float16)a0;
-    f1 = oob ? (_Float16)0 : (_Float16)a1;
+    f0 = oob ? (_Float16)0 : (HALF_ACC ? h0 : (_Float16)a0);
+    f1 = oob ? (_Float16)0 : (HALF_ACC ? h1 : (_Float16)a1);
 }
 
 // same values and arithmetic as net_density<2>; `pre` holds this tile's hashed-level entries on entry and the next tile's on exit
@@ -415,6 +424,48 @@ __device__ __forceinline__ void net_density_piped(const NetArgs& na, const _Floa
     sigma = expf((float)s16[0]);
 }
 
+// The gather of net_density on its own: a lane's four levels (q, q+4, q+8, q+12) -> 32 raw corner entries, the interpolation
+// fractions and the out-of-range flag.  (net_density keeps its own copy of these lines: its instruction schedule is tuned.)
+template <int MODE>
+__device__ __forceinline__ void fused_gather(const NetArgs& na, const LevelTab& lt, uint32_t q, float x, float y, float z, uint32_t (&raw)[4][8],
+                                             float (&fr)[4][3], bool& oob) {
+    float u[3];
+    encoder_unit(na, x, y, z, u, oob);
+    const float half_off = na.align_corners ? 0.0f : 0.5f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t level = q + 4 * i;
+        const float scale = lt.scale[level];
+        uint32_t g[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float p = fmaf(u[d], scale, half_off);
+            g[d] = (uint32_t)floorf(p);
+            fr[i][d] = p - (float)g[d];
+        }
+        if (MODE == 2 && i < 3) {
+            const uint32_t S = lt.cell_res[level];
+            const uint4* rec = na.cells + (size_t)(lt.cell_off[level] + g[0] + S * (g[1] + S * g[2])) * 2;
+            const uint4 lo = rec[0], hi = rec[1];
+            raw[i][0] = lo.x; raw[i][1] = lo.y; raw[i][2] = lo.z; raw[i][3] = lo.w;
+            raw[i][4] = hi.x; raw[i][5] = hi.y; raw[i][6] = hi.z; raw[i][7] = hi.w;
+            continue;
+        }
+        const uint32_t* tab = na.table + lt.offset[level];
+        const uint32_t a1 = lt.a1[level], a2 = lt.a2[level], mask = lt.mask[level], fl = lt.flags[level];
+        const bool hashed = (fl & 1u) != 0;
+        const uint32_t t1[2] = {g[1] * a1, g[1] * a1 + a1}, t2[2] = {g[2] * a2, g[2] * a2 + a2};
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const uint32_t px = g[0] + (idx & 1), ty = t1[(idx >> 1) & 1], tz = t2[(idx >> 2) & 1];
+            uint32_t e = hashed ? (px ^ ty ^ tz) : (px + ty + tz);
+            e &= mask;
+            if (MODE == 1) { if (fl & 2u) e %= lt.size[level]; }
+            raw[i][idx] = tab[e];
+        }
+    }
+}
+
 // colour half: SH degree 4 + geo_feat -> colour net -> fp16 sigmoid (results in q == 0)
 __device__ __forceinline__ void net_color(const NetArgs& na, const _Float16* Wlds, uint32_t lane, float dx, float dy, float dz,
                                           const _Float16 (&s16)[4], float& cr, float& cg, float& cb) {
@@ -468,6 +519,31 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
         lt->cell_res[l] = lv.resolution[l];
     }
     __syncthreads();
+}
+
+// Diagnostics: the 32 hash-grid features as the fused kernels form them ([M, 32] fp16 in the operator's order 2 * level + channel),
+// with the default arithmetic or with the operator's (HALF_ACC)
+template <int MODE, bool HALF_ACC>
+__global__ void __launch_bounds__(256) k_debug_features(NetArgs na, GridLevels lv, const float* __restrict__ xyzs, uint32_t M, _Float16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t tile = wave; tile < (M + 15) / 16; tile += n_waves) {
+        const uint32_t m = tile * 16 + c, mm = m < M ? m : M - 1;
+        uint32_t raw[4][8];
+        float fr[4][3];
+        bool oob;
+        fused_gather<MODE>(na, *lt, q, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], raw, fr, oob);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            _Float16 f0, f1;
+            corners_to_feature<HALF_ACC>(fr[i], raw[i], oob, f0, f1);
+            if (m < M) { out[(size_t)m * 32 + 2 * (q + 4 * i)] = f0; out[(size_t)m * 32 + 2 * (q + 4 * i) + 1] = f1; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -755,7 +831,6 @@ __global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetAr
     const half8* Wc = reinterpret_cast<const half8*>(Wlds + sig_halfs(na.sig_mm));
     const half8* Bs = reinterpret_cast<const half8*>(Wb);
     const half8* Bc = reinterpret_cast<const half8*>(Wb + bwd_halfs(na.sig_mm));
-    const float half_off = na.align_corners ? 0.0f : 0.5f;
 
     for (uint32_t ray = blockIdx.x * kGradWaves + wid; ray < ga.N; ray += gridDim.x * kGradWaves) {
         const float ox = ga.rays_o[(size_t)ray * 3], oy = ga.rays_o[(size_t)ray * 3 + 1], oz = ga.rays_o[(size_t)ray * 3 + 2];
@@ -850,44 +925,12 @@ __global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetAr
             const float ux = ox + dx * zv, uy = oy + dy * zv, uz = oz + dz * zv;          // before the clip (for its derivative)
             const float x = clampf(ux, ga.aabb_lo, ga.aabb_hi), y = clampf(uy, ga.aabb_lo, ga.aabb_hi), z = clampf(uz, ga.aabb_lo, ga.aabb_hi);
             // ---- forward recompute, keeping corners and activations
-            float u[3];
             bool oob;
-            encoder_unit(na, x, y, z, u, oob);
             uint32_t raw[4][8];
             float fr[4][3], scl[4];
+            fused_gather<MODE>(na, *lt, q, x, y, z, raw, fr, oob);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t level = q + 4 * i;
-                const float scale = lt->scale[level];
-                scl[i] = scale;
-                uint32_t g3[3];
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const float pz = fmaf(u[d], scale, half_off);
-                    g3[d] = (uint32_t)floorf(pz);
-                    fr[i][d] = pz - (float)g3[d];
-                }
-                if (MODE == 2 && i < 3) {
-                    const uint32_t S = lt->cell_res[level];
-                    const uint4* rec = na.cells + (size_t)(lt->cell_off[level] + g3[0] + S * (g3[1] + S * g3[2])) * 2;
-                    const uint4 lo = rec[0], hi = rec[1];
-                    raw[i][0] = lo.x; raw[i][1] = lo.y; raw[i][2] = lo.z; raw[i][3] = lo.w;
-                    raw[i][4] = hi.x; raw[i][5] = hi.y; raw[i][6] = hi.z; raw[i][7] = hi.w;
-                    continue;
-                }
-                const uint32_t* tab = na.table + lt->offset[level];
-                const uint32_t a1 = lt->a1[level], a2 = lt->a2[level], mask = lt->mask[level], fl = lt->flags[level];
-                const bool hashed = (fl & 1u) != 0;
-                const uint32_t t1[2] = {g3[1] * a1, g3[1] * a1 + a1}, t2[2] = {g3[2] * a2, g3[2] * a2 + a2};
-#pragma unroll
-                for (int k8 = 0; k8 < 8; k8++) {
-                    const uint32_t px = g3[0] + (k8 & 1), ty = t1[(k8 >> 1) & 1], tz = t2[(k8 >> 2) & 1];
-                    uint32_t en = hashed ? (px ^ ty ^ tz) : (px + ty + tz);
-                    en &= mask;
-                    if (MODE == 1) { if (fl & 2u) en %= lt->size[level]; }
-                    raw[i][k8] = tab[en];
-                }
-            }
+            for (int i = 0; i < 4; i++) scl[i] = lt->scale[q + 4 * i];
             half8 feat;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -2180,6 +2223,31 @@ int ngp_debug_disable_march_queue(int off) {
     std::lock_guard<std::mutex> lk(g_debug_mu);
     g_debug_default.flags = off;
     return NGP_OK;
+}
+
+int ngp_debug_fused_features(const ngp_model* model, const float* xyzs, uint32_t M, int operator_rounding, uint16_t* features, ngp_stream_t stream) {
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(xyzs && features, "debug_fused_features: null pointer");
+    NGP_REQUIRE(model && model->packed_weights, "debug_fused_features: model->packed_weights is NULL (ngp_pack_weights fills it)");
+    hipStream_t s = (hipStream_t)stream;
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
+    if (rc) return rc;
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab);
+    uint32_t blocks = div_up(div_up(M, 16), 4);
+    if (blocks > 1024) blocks = 1024;
+    const int mode = needs_generic(lv) ? 1 : (na.cells ? 2 : 0);
+#define NGP_DBG_FEAT(MODE_, HA_)                                                                              \
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_debug_features<MODE_, HA_>), 96 * 1024);               \
+    k_debug_features<MODE_, HA_><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, (_Float16*)features)
+    if (operator_rounding) {
+        if (mode == 1) { NGP_DBG_FEAT(1, true); } else if (mode == 2) { NGP_DBG_FEAT(2, true); } else { NGP_DBG_FEAT(0, true); }
+    } else {
+        if (mode == 1) { NGP_DBG_FEAT(1, false); } else if (mode == 2) { NGP_DBG_FEAT(2, false); } else { NGP_DBG_FEAT(0, false); }
+    }
+#undef NGP_DBG_FEAT
+    return check_launch("debug_fused_features");
 }
 
 int ngp_debug_set_grad_dump(float* device_buf) {

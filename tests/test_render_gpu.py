@@ -33,6 +33,14 @@ def _same_bits(a, b):
     return torch.equal(a, b)
 
 
+# fp16 parity bounds of the composited pixels against the oracle: TWICE what this build was observed to reach on these views
+# (MI355X; printed by the tests), not a generous constant -- a regression in the fused path's numerics shows up here first
+# observed (64x64, views 7 / 160): operators max 5.2e-5 mean 6.9e-8, depth 4.2e-7; fused max 8.0e-5 mean 4.6e-6, depth 9.2e-6
+OBS_MAX_RGB = {False: 1.1e-4, True: 1.6e-4}
+OBS_MEAN_RGB = {False: 1.4e-7, True: 9.2e-6}
+OBS_MAX_DEPTH = {False: 8.4e-7, True: 1.9e-5}
+
+
 @pytest.fixture(scope="module")
 def setup(device):
     sc = _scene()
@@ -104,9 +112,11 @@ def test_run_cuda_against_oracle(setup, device, view):
         assert out["image"].shape == (1, sc.H * sc.W, 3) and out["depth"].shape == (1, sc.H * sc.W)
         # pixels: <= 2e-3 absolute (fp16 network, see module docstring); mean error far smaller
         err = np.abs(img - want_img)
-        assert err.max() < 4e-3, (fused, err.max())
-        assert err.mean() < 2e-4, (fused, err.mean())
-        np.testing.assert_allclose(dep, want_depth, rtol=0, atol=4e-3)
+        derr = np.abs(dep - want_depth)
+        print(f"run_cuda vs oracle, view {view}, fused={fused}: max |dRGB| {err.max():.2e} mean {err.mean():.2e}; max |ddepth| {np.nanmax(derr):.2e}")
+        assert err.max() < OBS_MAX_RGB[fused], (fused, err.max())
+        assert err.mean() < OBS_MEAN_RGB[fused], (fused, err.mean())
+        np.testing.assert_allclose(dep, want_depth, rtol=0, atol=OBS_MAX_DEPTH[fused])
         # the reference's schedule: number of loop iterations and summed batch sizes.  Individual rays may terminate
         # one sample earlier/later when T lands within fp16 noise of 1e-4, so allow 0.2 % on the totals.
         assert abs(stats["iterations"] - want["iterations"]) <= 2, (fused, stats, want["iterations"])
@@ -472,7 +482,9 @@ def test_full_size_frame_properties(device, bound, radius, view):
                               sc.density_scale)
     want_img = want["image"] + (1 - want["weights_sum"])[:, None] * 1.0
     err = np.abs(img.cpu().numpy()[sel] - want_img)
-    assert err.max() < 4e-3 and err.mean() < 2e-4, (err.max(), err.mean())
+    print(f"full-size frame bound {bound}: every 97th ray vs oracle: max |dRGB| {err.max():.2e} mean {err.mean():.2e}")
+    # observed: 9.9e-4 max (a handful of rays whose last sample sits within fp16 noise of the T < 1e-4 stop), 3.2e-6 mean -> 2 x
+    assert err.max() < 2e-3 and err.mean() < 1e-5, (err.max(), err.mean())
     same = h_full.cpu().numpy().view(np.uint32)[sel] == want["sample_hash"]
     assert same.mean() > 0.995, same.mean()
     missed = want["nears"] >= want["fars"]
@@ -714,3 +726,47 @@ def test_run_path_exit_is_taken_by_whole_waves(device):
     assert float((fused["depth"].float() - ops["depth"].float()).abs().max()) < 5e-3
     np.testing.assert_allclose(fused["aggregated_density"].float().cpu().numpy(), ops["aggregated_density"].float().cpu().numpy(), rtol=2e-2, atol=1e-3)
     assert float((fused["image"].float() - ops["image"].float()).abs().mean()) < 5e-3
+
+
+def test_fused_gather_vs_grid_encode_operator(device):
+    """What the fused kernels' one-rounding corner accumulation changes relative to the reference arithmetic, MEASURED: through the
+    fused gather (per-cell records + hashed gathers) with the operator's c10::Half rounding the 32 features equal grid_encode's bit
+    for bit; with the default fp32 accumulation they differ by at most one fp16 ulp of the feature."""
+    import ctypes as C
+    from nerfsafetyvalidation_amd import _lib
+    sc = _scene(H=16, W=16)
+    model = sc.build_model(device)
+    fm = model.fused_model()
+    fm._ensure_cells()
+    assert fm._cell_levels == 12
+    rng = np.random.default_rng(3)
+    M = 20000
+    xyz = rng.uniform(-sc.bound, sc.bound, (M, 3)).astype(np.float32)
+    xyz[0], xyz[1], xyz[2] = sc.bound, -sc.bound, 0.0
+    xyz[1000:1512] = (xyz[1000:1001] * 0.2 + np.linspace(0, 1.2, 512)[:, None] * np.array([0.4, 0.5, 0.76], np.float32)).astype(np.float32)   # a ray
+    x = _t(xyz, device)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        want = model.encoder(x, bound=model.bound)                        # the grid_encode operator (bit-exact against the oracle elsewhere)
+    lib, m = _lib.lib(), fm._struct(None)
+    got = {}
+    for mode in (1, 0):
+        out = torch.empty(M, 32, dtype=torch.float16, device=device)
+        _lib.check(lib.ngp_debug_fused_features(C.byref(m), _lib.ptr(x), M, mode, _lib.ptr(out), _lib.stream()), "debug_fused_features")
+        got[mode] = out
+    assert torch.equal(got[1], want)                                          # same gather, operator rounding: bit-identical
+    a, b = got[0].float().cpu().numpy(), want.float().cpu().numpy()
+    d = np.abs(a - b)
+    same = float((got[0] == want).float().mean())
+    # the yardstick: one fp16 ulp at the magnitude of the table entries being interpolated (|entry| < 0.5 here: 2^-11); the operator
+    # rounds each of its 8 products and 8 partial sums at up to half of that
+    ulp_tab = 2.0 ** -11
+    # ... and which of the two is closer to the interpolation evaluated in fp32 on the same fp16 table (oracle, f32 table path)
+    enc = model.encoder
+    emb32 = enc.embeddings.detach().half().float().cpu().numpy()
+    exact, _ = Hh.oracle_grid_encode(Hh.encoder_input(xyz, sc.bound), emb32, enc.offsets.cpu().numpy().astype(np.int32), enc.per_level_scale)
+    err_fused, err_op = np.abs(a - exact), np.abs(b - exact)
+    print(f"fused gather vs grid_encode: {same:.4f} of the features bit-identical, max |diff| {d.max():.3e} = {d.max() / ulp_tab:.2f} ulp(table), "
+          f"mean |diff| {d.mean():.3e}; error against the fp32 interpolation: fused mean {err_fused.mean():.3e} max {err_fused.max():.3e}, "
+          f"operator mean {err_op.mean():.3e} max {err_op.max():.3e}")
+    assert d.max() <= 2.0 * ulp_tab and d.mean() < 1e-4 and same > 0.3
+    assert err_fused.mean() < err_op.mean() and err_fused.max() <= 0.51 * ulp_tab * 2     # one rounding of a value below 1: <= half an ulp of 1.0
