@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the library shares)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libngp_hip.so")
+SO_PATH = os.environ.get("NGP_HIP_LIB", os.path.join(_HERE, "libngp_hip.so"))   # (the override: A/B builds of experiments, scripts/build_variant.sh)
 
 NGP_F32, NGP_F16 = 0, 1
 

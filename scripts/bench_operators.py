@@ -82,7 +82,8 @@ line("ffmlp_backward (both nets, averaged: activation chain + split-K weight gra
      (32 + 64 + 2.5 * 128 * 2 + 64 + 2.5 * 128 * 2 + 32) * Mp, flops_per_call=2 * (14336 + 22528) / 2 * Mp,
      note="bytes: chain reads grad 32 + stored activations, writes activation gradients + input gradient 64; weight-gradient pass reads "
           "inputs 64, activations and activation gradients again, grad 32")
-line("sh_encode_backward", "sh_encode_backward", Mp, "points", (64 + 192 + 12) * Mp)
+# (sh_encode_backward is not launched by a training step -- view directions carry no gradient there -- it is timed below, on
+#  the pose-gradient shape where it does run)
 line("grid_encode_backward f16 (table gradient, packed-half atomics)", "grid_encode_backward", Mp, "points", 588 * Mp)
 line("adam_step (all parameters, averaged over the 3 tensors)", "adam_step", n_param / 3, "params", 28 * n_param / 3)
 
@@ -109,6 +110,21 @@ with torch.no_grad():
         S = N * n_step
         line(f"march_rays n_alive={N} n_step={n_step}", "march_rays", S, "sample_slots", 32 * S + (4 + 4 + 24 + 8) * N)
         line(f"composite_rays n_alive={N} n_step={n_step}", "composite_rays", S, "sample_slots", 24 * S + (4 + 4 + 2 * 20 + 4) * N)
+    # sh_encode_backward: the direction gradient of the estimator's pose fit (dirs require grad), on a frame's worth of samples
+    from nerfsafetyvalidation_amd.shencoder import SHEncoder
+    enc_sh = SHEncoder(degree=4)
+    with torch.enable_grad():
+        dd = torch.nn.functional.normalize(torch.randn(Mp, 3, device=dev), dim=-1).requires_grad_(True)
+        gsh = torch.randn(Mp, 16, device=dev)
+        enc_sh(dd).backward(gsh)
+        torch.cuda.synchronize(); lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
+        for _ in range(5):
+            dd.grad = None
+            enc_sh(dd).backward(gsh)
+        torch.cuda.synchronize(); lib.ngp_prof_enable(0)
+    line("sh_encode_backward deg 4", "sh_encode_backward", Mp, "points", (64 + 192 + 12 + 12) * Mp,
+         note="bytes: grad 64 + dy_dx 192 read, grad_inputs 12 read-modify-write")
+    # the sample bookkeeping of `run` and the fused differentiable `run` on the estimator's shape (1024 rays x 512 samples)
     grid = torch.rand(model.cascade * model.grid_size ** 3, device=dev)
     torch.cuda.synchronize(); lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
     for _ in range(5):
