@@ -51,12 +51,16 @@ def parse():
     return p.parse_args()
 
 
+PMC_SUMMARY = "r02_pmc.json"                    # scripts/profile_round.sh, copied into profiles/ at the end of the round
+KERNEL_STATS = "r02_bench_kernel_stats.csv"
+
+
 def pmc_traffic_per_launch():
     """HBM-side bytes per k_render_iter launch from the committed rocprofv3 --pmc summary of this same command (profiles/, one
     counter pass each for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, whose
     counter tallies 128-byte requests at 64 bytes).  Counters cannot be collected from inside this process; None when no
     summary is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_latest.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_SUMMARY)
     try:
         with open(path) as fh:
             k = next(v for name, v in json.load(fh).items() if "k_render_iter" in name)
@@ -259,11 +263,11 @@ def main():
                 achieved = algo_bytes / (ms.value * 1e-3) / 1e9
                 roof = {"kernel": "k_render_iter (fused march+hashgrid+MLPs+composite)", "bound": "hbm",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic_per_launch(), "traffic_unit": "bytes per launch (profiles/r01_pmc_latest.json: FETCH_SIZE x2 + WRITE_SIZE)",
+                        "traffic": pmc_traffic_per_launch(), "traffic_unit": f"bytes per launch (profiles/{PMC_SUMMARY}: FETCH_SIZE x2 + WRITE_SIZE)",
                         "achieved_bytes_per_launch": round(algo_bytes / n_launch.value), "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
                         "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
                         "measured_with": "one frame in flight (separate single-stream pass; rocprofv3 twin: `bench.py --in-flight 1`, "
-                                         "profiles/r01_bench_kernel_stats_v9.csv).  With several frames in flight the streams' launches overlap "
+                                         f"profiles/{KERNEL_STATS}).  With several frames in flight the streams' launches overlap "
                                          "and their durations are not additive",
                         "algorithmic_bytes_per_sample": TABLE_BYTES_PER_SAMPLE, "algorithmic_bytes_per_ray_iteration": RAY_BYTES_PER_RAY_ITER}
 
