@@ -165,6 +165,10 @@ NGP_API int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, con
                        int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
                        uint16_t* grad_weights, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 NGP_API size_t ngp_ffmlp_backward_workspace(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
+/* backward_buffer is scratch in the reference (ffmlp/ffmlp.py:70 allocates it, nothing reads it after the call).  The 64-wide
+ * networks compute activation and weight gradients in one pass and never need it in memory: this returns the bytes a caller has
+ * to provide -- 0 when backward_buffer may be NULL (a non-NULL buffer is still filled, as documented above). */
+NGP_API size_t ngp_ffmlp_backward_buffer_bytes(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
 /* ffmlp.cu:721-741: the reference creates CUTLASS split-K streams/events here.  Both are no-ops kept for the interface
  * (ffmlp/ffmlp.py:126 calls allocate_splitk from FFMLP.__init__): this library has no split-K state of its own. */
 NGP_API int ngp_ffmlp_allocate_splitk(size_t n);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ngp_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "ngp_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp, _vp, _sz, _vp],
     "ngp_ffmlp_backward_workspace": [_u32, _u32, _u32, _u32],
+    "ngp_ffmlp_backward_buffer_bytes": [_u32, _u32, _u32, _u32],
     "ngp_ffmlp_allocate_splitk": [_sz],
     "ngp_ffmlp_free_splitk": [],
     "ngp_get_rays": [_vp, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _u32, _vp, _vp, _vp],
@@ -109,7 +110,7 @@ SIGNATURES = {
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
 _RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_packed_weights_bwd_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
-             "ngp_ffmlp_backward_workspace": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
+             "ngp_ffmlp_backward_workspace": _sz, "ngp_ffmlp_backward_buffer_bytes": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
 
 _lib = None
 

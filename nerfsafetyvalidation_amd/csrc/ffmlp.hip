@@ -19,6 +19,8 @@
 // reference accumulates in fp16 inside WMMA (OUT_T = __half, ffmlp.cu:564).
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "ngp_common.hpp"
@@ -508,6 +510,233 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_chain(const _Float16* __restr
     }
 }
 
+// ---- the 64-wide networks: activation gradients AND weight gradients in one pass ---------------------------------------------
+// k_ffmlp_bwd_chain writes every layer's activation gradients to HBM only for k_ffmlp_bwd_wgrad to read them back together with
+// the stored activations: 1472 bytes per row move where 480 are needed (grad 32 + activations 128 per layer + inputs 64 + the
+// input gradient 64).  Here a workgroup keeps both operands of the weight-gradient products in LDS while the chain has them in
+// registers anyway: per group of 128 rows (4 waves x 2 tiles of 16) and per matrix, the waves put their activation-gradient tiles
+// and the matching activation tiles into two shared [128 x 64] LDS images, and wave w accumulates the output-row block w of
+// dW = G^T X over all 128 rows with v_mfma_f32_16x16x32_f16, both operands read with the transposing ds_read_b64_tr_b16 (two
+// 16-row tiles concatenated along k).  The accumulators (1 + 4 NL + in_dim / 16 fragments per wave) stay in registers for the
+// whole persistent loop; each workgroup ends by writing one fp32 partial of every parameter, k_ffmlp_bwd_reduce sums the
+// partials in a fixed order.  The activation gradients are rounded to fp16 exactly where the two-kernel form rounds them.
+// NL = hidden matrices (num_layers - 1).
+constexpr uint32_t kFusedTPW = 2, kFusedRows = 4 * kFusedTPW * 16;
+__device__ __forceinline__ half8v tr_pair(const _Float16* p, uint32_t stride16) {   // two 16-row tiles, k = 0..31
+    return cat8(lds_tr_read(p), lds_tr_read(p + stride16));
+}
+template <int NL>
+__global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
+                                                         const _Float16* __restrict__ weights, const _Float16* __restrict__ fwd, uint32_t B,
+                                                         uint32_t in_dim, uint32_t act, _Float16* __restrict__ bwd,
+                                                         _Float16* __restrict__ grad_inputs, uint32_t n_groups, float* __restrict__ ws, uint32_t P) {
+    constexpr uint32_t HB = 4, HID = 64, SH = 80, TPW = kFusedTPW, L = NL + 1;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const uint32_t sIn = lds_stride(in_dim), IB = in_dim >> 4;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const uint32_t tr_row = 4 * g + (c >> 2), tr_col = 4 * (c & 3);
+    const uint32_t trl_H = tr_row * SH + tr_col, trl_I = tr_row * sIn + tr_col;
+    const _Float16* W_in = weights;
+    const _Float16* W_hid = weights + (size_t)HID * in_dim;
+    const _Float16* W_out = W_hid + (size_t)NL * HID * HID;
+    const uint32_t off_hid = 16 * SH, off_in = off_hid + NL * HID * SH, off_G = off_in + HID * sIn, off_X = off_G + kFusedRows * SH;
+    _Float16* Gt = lds + off_G;
+    _Float16* Xt = lds + off_X;
+    const size_t BH = (size_t)B * HID;
+    const uint32_t n_tiles = B >> 4;
+    stage_matrix(lds, W_out, 16, HID, SH);
+    for (uint32_t m = 0; m < (uint32_t)NL; m++) stage_matrix(lds + off_hid + m * HID * SH, W_hid + (size_t)m * HID * HID, HID, HID, SH);
+    if (grad_inputs) stage_matrix(lds + off_in, W_in, HID, in_dim, sIn);
+    __syncthreads();
+    f32x4 aO = (f32x4){0, 0, 0, 0}, aH[NL][HB], aI[HB];
+#pragma unroll
+    for (int i = 0; i < HB; i++) {
+        aI[i] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < NL; m++) aH[m][i] = (f32x4){0, 0, 0, 0};
+    }
+    const half4 zero4 = (half4){0, 0, 0, 0};
+    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+        size_t row[TPW];
+        bool valid[TPW];
+        uint32_t lrow[TPW];                     // this lane's row of the shared images
+#pragma unroll
+        for (int t = 0; t < (int)TPW; t++) {
+            const uint32_t tile = (group * 4 + wave) * TPW + t;
+            valid[t] = tile < n_tiles;
+            row[t] = (size_t)(valid[t] ? tile : n_tiles - 1) * 16 + c;
+            lrow[t] = ((wave * TPW + t) * 16 + c) * SH;
+        }
+        // ---- output matrix: dH_last^T = W_out^T * grad^T; dW_out = grad^T * fwd[L-1] ----
+        half4 dh[TPW][HB];
+        {
+            half4 gB[TPW], fl[TPW][HB];
+            const _Float16* f = fwd + (size_t)(L - 1) * BH;
+#pragma unroll
+            for (int t = 0; t < (int)TPW; t++) {
+                gB[t] = ld_half4(grad + row[t] * 16 + g * 4);
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++) fl[t][ib] = ld_half4(f + row[t] * HID + ib * 16 + g * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < (int)TPW; t++) {
+                st_half4(Gt + lrow[t] + g * 4, valid[t] ? gB[t] : zero4);
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++) st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? fl[t][ib] : zero4);
+            }
+#pragma unroll
+            for (int ib = 0; ib < HB; ib++) {
+                const half4 a = lds_tr_read(lds + trl_H + ib * 16);
+#pragma unroll
+                for (int t = 0; t < (int)TPW; t++) {
+                    const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, gB[t], (f32x4){0, 0, 0, 0}, 0, 0, 0);
+                    dh[t][ib] = transfer_pack(act, acc, fl[t][ib]);
+                    if (bwd && valid[t]) st_half4(bwd + row[t] * HID + ib * 16 + g * 4, dh[t][ib]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t ks = 0; ks < kFusedRows / 32; ks++)
+                aO = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_pair(Gt + ks * 32 * SH + trl_H, 16 * SH),
+                                                            tr_pair(Xt + ks * 32 * SH + trl_H + wave * 16, 16 * SH), aO, 0, 0, 0);
+            __syncthreads();
+        }
+        // ---- hidden matrices, last to first: dW_hid[m] = dH_{m+1}^T * fwd[m]; dH_m^T = W_hid[m]^T * dH_{m+1}^T ----
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int m = NL - 1 - k;
+            const _Float16* Wl = lds + off_hid + m * HID * SH;
+            const _Float16* f = fwd + (size_t)m * BH;
+            half4 fm[TPW][HB];
+#pragma unroll
+            for (int t = 0; t < (int)TPW; t++)
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++) fm[t][ib] = ld_half4(f + row[t] * HID + ib * 16 + g * 4);
+#pragma unroll
+            for (int t = 0; t < (int)TPW; t++)
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++) {
+                    st_half4(Gt + lrow[t] + ib * 16 + g * 4, valid[t] ? dh[t][ib] : zero4);
+                    st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? fm[t][ib] : zero4);
+                }
+            half4 dn[TPW][HB];
+#pragma unroll
+            for (int ib = 0; ib < HB; ib++) {
+                f32x4 acc[TPW];
+#pragma unroll
+                for (int t = 0; t < (int)TPW; t++) acc[t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) {
+                    const half4 a = lds_tr_read(Wl + trl_H + ob * 16 * SH + ib * 16);
+#pragma unroll
+                    for (int t = 0; t < (int)TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, dh[t][ob], acc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < (int)TPW; t++) {
+                    dn[t][ib] = transfer_pack(act, acc[t], fm[t][ib]);
+                    if (bwd && valid[t]) st_half4(bwd + (size_t)(k + 1) * BH + row[t] * HID + ib * 16 + g * 4, dn[t][ib]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t ks = 0; ks < kFusedRows / 32; ks++) {
+                const half8v a = tr_pair(Gt + ks * 32 * SH + trl_H + wave * 16, 16 * SH);
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++)
+                    aH[m][ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, tr_pair(Xt + ks * 32 * SH + trl_H + ib * 16, 16 * SH), aH[m][ib], 0, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < (int)TPW; t++)
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++) dh[t][ib] = dn[t][ib];
+        }
+        // ---- input matrix: dW_in = dH_0^T * inputs ----
+#pragma unroll
+        for (int t = 0; t < (int)TPW; t++)
+#pragma unroll
+            for (int ib = 0; ib < HB; ib++) {
+                st_half4(Gt + lrow[t] + ib * 16 + g * 4, valid[t] ? dh[t][ib] : zero4);
+                if (ib < (int)IB) {
+                    const half4 x = ld_half4(inputs + row[t] * in_dim + ib * 16 + g * 4);
+                    st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? x : zero4);
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t ks = 0; ks < kFusedRows / 32; ks++) {
+            const half8v a = tr_pair(Gt + ks * 32 * SH + trl_H + wave * 16, 16 * SH);
+#pragma unroll
+            for (int ib = 0; ib < HB; ib++)
+                if (ib < (int)IB)
+                    aI[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, tr_pair(Xt + ks * 32 * SH + trl_H + ib * 16, 16 * SH), aI[ib], 0, 0, 0);
+        }
+        // ---- dL/dinput = dH_0 * W_in ----
+        if (grad_inputs) {
+            const _Float16* Wl = lds + off_in;
+            for (uint32_t ib = 0; ib < IB; ib++) {
+                f32x4 acc[TPW];
+#pragma unroll
+                for (int t = 0; t < (int)TPW; t++) acc[t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) {
+                    const half4 a = lds_tr_read(Wl + trl_I + ob * 16 * sIn + ib * 16);
+#pragma unroll
+                    for (int t = 0; t < (int)TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, dh[t][ob], acc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < (int)TPW; t++) {
+                    half4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h[r] = (_Float16)acc[t][r];
+                    if (valid[t]) st_half4(grad_inputs + row[t] * in_dim + ib * 16 + g * 4, h);
+                }
+            }
+        }
+        __syncthreads();      // the images are rewritten by the next group
+    }
+    // ---- this workgroup's partial of every parameter (fp32, the parameter blob's layout) ----
+    float* out = ws + (size_t)blockIdx.x * P;
+#pragma unroll
+    for (int ib = 0; ib < HB; ib++)
+        if (ib < (int)IB) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(size_t)(wave * 16 + 4 * g + r) * in_dim + ib * 16 + c] = aI[ib][r];
+        }
+#pragma unroll
+    for (int m = 0; m < NL; m++)
+#pragma unroll
+        for (int ib = 0; ib < HB; ib++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(size_t)HID * in_dim + (size_t)m * HID * HID + (size_t)(wave * 16 + 4 * g + r) * HID + ib * 16 + c] = aH[m][ib][r];
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[(size_t)HID * in_dim + (size_t)NL * HID * HID + (size_t)(4 * g + r) * HID + wave * 16 + c] = aO[r];
+}
+
+static size_t fused_bwd_lds_bytes(uint32_t in_dim, uint32_t NL) {
+    return ((size_t)16 * 80 + (size_t)NL * 64 * 80 + (size_t)64 * lds_stride(in_dim) + 2 * (size_t)kFusedRows * 80) * sizeof(_Float16);
+}
+static uint32_t fused_bwd_blocks(uint32_t B, uint32_t in_dim, uint32_t NL) {
+    const uint32_t n_groups = div_up(B / 16, 4 * kFusedTPW);
+    const uint32_t per_cu = fused_bwd_lds_bytes(in_dim, NL) <= 80 * 1024 ? 2 : 1;
+    return n_groups < 256 * per_cu ? n_groups : 256 * per_cu;
+}
+static bool fused_bwd_applies(uint32_t in_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    static const bool off = getenv("NGP_FFMLP_NO_FUSED_BWD") != nullptr;     // diagnostics: the two-kernel form for every shape
+    return !off && hidden_dim == 64 && num_layers >= 2 && num_layers <= 4 && in_dim <= 64;
+}
+template <int NL>
+static void launch_bwd_fused(const uint16_t* grad, const uint16_t* inputs, const uint16_t* w, const uint16_t* fwd, uint32_t B, uint32_t in_dim,
+                             uint32_t act, uint16_t* bwd, uint16_t* gi, float* ws, uint32_t P, hipStream_t s) {
+    const size_t lds = fused_bwd_lds_bytes(in_dim, NL);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_ffmlp_bwd_fused<NL>), 160 * 1024);
+    const uint32_t n_groups = div_up(B / 16, 4 * kFusedTPW);
+    k_ffmlp_bwd_fused<NL><<<fused_bwd_blocks(B, in_dim, NL), 256, lds, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)w,
+                                                                            (const _Float16*)fwd, B, in_dim, act, (_Float16*)bwd, (_Float16*)gi,
+                                                                            n_groups, ws, P);
+}
+
 // One wave per workgroup.  blockIdx.x = batch chunk, blockIdx.y = unit: up to 4x4 output fragments of one matrix.
 __global__ void __launch_bounds__(64) k_ffmlp_bwd_wgrad(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
                                                         const _Float16* __restrict__ fwd, const _Float16* __restrict__ bwd, uint32_t B,
@@ -680,7 +909,7 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
     (void)output_activation;  // not transferred by the reference either (ffmlp.cu:462-464); FFMLP always passes `none`
     if (B == 0) return NGP_OK;
     hipStream_t s = (hipStream_t)stream;
-    NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights, "ffmlp_backward: null pointer");
+    NGP_REQUIRE(grad && inputs && weights && forward_buffer && grad_weights, "ffmlp_backward: null pointer");
     NGP_REQUIRE(!calc_grad_inputs || grad_inputs, "ffmlp_backward: calc_grad_inputs without a grad_inputs buffer");
     NGP_REQUIRE(B % 16 == 0, "ffmlp_backward: batch size must be a multiple of 16 (got %u)", B);
     NGP_REQUIRE(input_dim > 0 && input_dim % 16 == 0, "FFMLP input_dim should be 16 * m (m > 0), but got %u", input_dim);
@@ -693,10 +922,24 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
     NGP_REQUIRE(workspace && workspace_bytes >= (size_t)P * 4 && ((uintptr_t)workspace & 15) == 0,
                 "ffmlp_backward: split-K workspace missing, misaligned or smaller than one set of partials (%zu < %zu bytes); "
                 "ngp_ffmlp_backward_workspace() gives the size", workspace_bytes, (size_t)P * 4);
-    uint32_t S;
-    const uint32_t chunk = splitk_plan(B, P, workspace_bytes, S);
     float* ws = reinterpret_cast<float*>(workspace);
     ProfScope prof("ffmlp_backward", s, B);
+    if (fused_bwd_applies(input_dim, hidden_dim, num_layers) &&
+        workspace_bytes >= (size_t)fused_bwd_blocks(B, input_dim, num_layers - 1) * P * 4) {
+        const uint32_t S = fused_bwd_blocks(B, input_dim, num_layers - 1);
+        switch (num_layers) {
+            case 2: launch_bwd_fused<1>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
+            case 3: launch_bwd_fused<2>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
+            default: launch_bwd_fused<3>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
+        }
+        int rc = check_launch("ffmlp_backward (activation and weight gradients)");
+        if (rc) return rc;
+        k_ffmlp_bwd_reduce<<<div_up(P, 64), 64 * kReduceWaves, 0, s>>>(ws, S, P, (_Float16*)grad_weights);
+        return check_launch("ffmlp_backward (split-K reduction)");
+    }
+    NGP_REQUIRE(backward_buffer, "ffmlp_backward: this shape takes the two-kernel form, which needs backward_buffer");
+    uint32_t S;
+    const uint32_t chunk = splitk_plan(B, P, workspace_bytes, S);
     switch (hidden_dim) {
         case 16: launch_bwd_chain<1, 4>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
         case 32: launch_bwd_chain<2, 4>(grad, weights, forward_buffer, B, input_dim, num_layers, activation, backward_buffer, gi, s); break;
@@ -720,7 +963,15 @@ size_t ngp_ffmlp_backward_workspace(uint32_t B, uint32_t input_dim, uint32_t hid
     const uint32_t P = ffmlp_params(input_dim, hidden_dim, num_layers);
     uint32_t S;
     (void)splitk_plan(B ? B : 16, P, (size_t)256 << 20, S);
+    if (fused_bwd_applies(input_dim, hidden_dim, num_layers)) {
+        const uint32_t blocks = fused_bwd_blocks(B ? B : 16, input_dim, num_layers - 1);
+        S = S > blocks ? S : blocks;
+    }
     return (size_t)S * P * 4;
+}
+
+size_t ngp_ffmlp_backward_buffer_bytes(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    return fused_bwd_applies(input_dim, hidden_dim, num_layers) ? 0 : (size_t)num_layers * B * hidden_dim * sizeof(_Float16);
 }
 
 // The reference creates its CUTLASS split-K side streams and events here (ffmlp.cu:721-741).  This library keeps no state

@@ -19,6 +19,8 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
+#include <stdio.h>
 
 #include "ngp_common.hpp"
 
@@ -409,15 +411,61 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restric
     }
 }
 
-// One level whose gradient slice (entries x C floats) fits the LDS: persistent workgroups accumulate their share of the batch
-// in LDS and add the slice to the table once.  blockIdx.y = index into the list of such levels.
+// lane <- lane - N inside rows of 16 lanes (DPP row_shr); lanes without a source keep `self`
+template <int N>
+__device__ __forceinline__ uint32_t row_shr_u32(uint32_t self, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)self, (int)v, 0x110 + N, 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ float row_shr_f32(float self, float v) {
+    return __uint_as_float(row_shr_u32<N>(__float_as_uint(self), __float_as_uint(v)));
+}
+// one round of the segmented inclusive sum over rows of 16 lanes: lanes whose run has not reached its head yet take the
+// partial sum N lanes below.  `open` = 1 while the head of the lane's run lies further down.
+template <int N, int V>
+__device__ __forceinline__ void row_segsum_round(float (&v)[V], uint32_t& open) {
+    const uint32_t below_open = row_shr_u32<N>(0u, open);
+    const bool take = open != 0 && (threadIdx.x & 15u) >= (uint32_t)N;
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+        const float o = row_shr_f32<N>(0.0f, v[i]);
+        v[i] += take ? o : 0.0f;
+    }
+    open = take ? below_open : 0u;
+}
+
+// The 2^D corner updates of neighbouring lanes (inside rows of 16) whose points lie in the same cell, summed onto the last lane of
+// each run: all corners coincide, one segmented sum serves them all.  Returns true on the lanes that now carry a run's total.
+template <int D, int V>
+__device__ __forceinline__ bool merge_cell_rows(bool valid, const uint32_t (&pg)[D], float (&v)[V]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    bool same = valid && (threadIdx.x & 15u) != 0;
+    same = same && row_shr_u32<1>(0u, (uint32_t)valid) != 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) same = same && row_shr_u32<1>(~0u, pg[d]) == pg[d];
+    const unsigned long long heads = __ballot(!same);
+    if (heads != ~0ull) {
+        uint32_t open = same ? 1u : 0u;
+        row_segsum_round<1>(v, open);
+        row_segsum_round<2>(v, open);
+        row_segsum_round<4>(v, open);
+        row_segsum_round<8>(v, open);
+    }
+    return valid && (lane == 63 || ((heads >> (lane + 1)) & 1ull));
+}
+
+// One level whose gradient slice fits the LDS: persistent workgroups accumulate their share of the batch in LDS and add the slice
+// to the table once.  blockIdx.y = index into the list of such levels.  For fp16 tables the accumulators are 64-bit fixed point
+// (units of 2^-30; |sum| < 2^33, i.e. 131 072 updates of the largest finite half on ONE entry): integer LDS atomics run at about ten times the rate of ds_add_f32 on gfx950, and
+// the slice does not depend on the order of the additions.
 constexpr int kSmallThreads = 1024;
-constexpr uint32_t kSmallMaxFloats = 30 * 1024;     // 120 KB of the 160 KB LDS
+constexpr uint32_t kSmallMaxFloats = 15 * 1024;     // accumulators: 120 KB of the 160 KB LDS
+constexpr float kSmallScale = 0x1p30f, kSmallInvScale = 0x1p-30f;
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                                        T* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
                                                                        bool align_corners, uint32_t small_mask) {
-    extern __shared__ float acc[];
+    extern __shared__ unsigned long long acc[];
     uint32_t level = 0, seen = 0;
     for (uint32_t l = 0; l < (uint32_t)kMaxLevels; l++)
         if ((small_mask >> l) & 1u) {
@@ -428,7 +476,7 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
     const uint32_t resolution = lv.resolution[level];
     const uint32_t n = hashmap_size * C;
-    for (uint32_t i = threadIdx.x; i < n; i += kSmallThreads) acc[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += kSmallThreads) acc[i] = 0ull;
     __syncthreads();
     const uint32_t n_pb = (B + kSmallThreads - 1) / kSmallThreads;
     for (uint32_t pb = blockIdx.x; pb < n_pb; pb += gridDim.x) {
@@ -445,22 +493,27 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
 #pragma unroll
             for (int c = 0; c < C; c++) g[c] = (float)gv.v[c];
         }
+        float v[(1 << D) * C];
 #pragma unroll
         for (int idx = 0; idx < (1 << D); idx++) {
             float w = 1;
-            uint32_t pl[D];
 #pragma unroll
-            for (int d = 0; d < D; d++) {
-                w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
-                pl[d] = pg[d] + ((idx >> d) & 1);
-            }
-            const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
-            float v[C];
+            for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
 #pragma unroll
-            for (int c = 0; c < C; c++) v[c] = w * g[c];
-            if (combine_runs<C>(e, valid, v)) {
+            for (int c = 0; c < C; c++) v[idx * C + c] = w * g[c];
+        }
+        if (merge_cell_rows<D>(valid, pg, v)) {
 #pragma unroll
-                for (int c = 0; c < C; c++) atomicAdd(&acc[e * C + c], v[c]);
+            for (int idx = 0; idx < (1 << D); idx++) {
+                uint32_t pl[D];
+#pragma unroll
+                for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
+                const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    if constexpr (sizeof(T) == 2) atomicAdd(&acc[e * C + c], (unsigned long long)__float2ll_rn(v[idx * C + c] * kSmallScale));
+                    else atomicAdd(reinterpret_cast<float*>(acc) + e * C + c, v[idx * C + c]);     // fp32 tables: no bound on the gradients' range
+                }
             }
         }
     }
@@ -469,50 +522,86 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
         float v[C];
         bool any = false;
 #pragma unroll
-        for (int c = 0; c < C; c++) { v[c] = acc[e * C + c]; any |= v[c] != 0.0f; }
+        for (int c = 0; c < C; c++) {
+            if constexpr (sizeof(T) == 2) {
+                const long long a = (long long)acc[e * C + c];
+                v[c] = (float)a * kSmallInvScale;
+            } else {
+                v[c] = reinterpret_cast<const float*>(acc)[e * C + c];
+            }
+            any |= v[c] != 0.0f;
+        }
         if (any) table_add<T, C>(tab, e, v);
     }
 }
 
-// ---- binned scatter for the hashed levels (fp16 table, C = 2) ------------------------------------------------------------
+// ---- binned scatter (fp16 table, C = 2) -----------------------------------------------------------------------------------
 // A hashed level spreads a batch's updates uniformly over its 2^19 entries: no two lanes agree, every update is its own
 // scattered atomic (~17 G/s chip-wide, the memory-side atomic unit handles one 64-byte request per update).  Two streaming
 // passes replace them:
-//  1. k_grid_bwd_bin: a workgroup of 1024 points computes its 8192 updates and sorts them in LDS into bins of 4096 consecutive
-//     entries (fixed capacity per bin, 1.5 x the mean; the rare overflow falls back to the atomic), then writes each bin's
-//     records (entry-in-bin, two fp16 values: 8 bytes) to its own segment of a workspace -- contiguous runs, plain stores;
-//  2. k_grid_bwd_bin_reduce: the workgroups that own a bin read its segments, accumulate in LDS (fp32) and add the 4096-entry
-//     slice to the table with coalesced atomics (256 contiguous bytes per wave instruction: the full atomic rate).
+//  1. k_grid_bwd_bin: a workgroup of NT points merges the updates of neighbouring samples that share a cell (DPP segmented
+//     sums inside 16-lane rows: samples arrive in ray order), counting-sorts what is left in LDS by bin (4096 consecutive
+//     entries), reserves room in each bin's region of the workspace with one global atomic per bin and appends its runs there:
+//     records of 8 bytes (entry-in-bin, two fp16 values), plain contiguous stores;
+//  2. k_grid_bwd_bin_reduce: the workgroups that own a bin stream its region (one contiguous array), accumulate in LDS (fp32)
+//     and add the 4096-entry slice to the table with coalesced atomics (256 contiguous bytes per wave instruction).
+// A region that fills up (degenerate inputs) sends the excess straight to the table with atomics.
 constexpr uint32_t kBinLog = 12, kBinEntries = 1u << kBinLog;    // entries per bin
 constexpr uint32_t kBinMax = 128;                                // bins per level (levels of at most 2^19 entries)
-constexpr uint32_t kBinCap = 96;                                 // records per (point block, bin)
-constexpr uint32_t kBinPoints = 1024;                            // points per k_grid_bwd_bin workgroup (one per thread)
-constexpr uint32_t kBinSplit = 8;                                // reducing workgroups per bin (fewer for small batches)
-// entry -> (bin, slot in the bin).  Hashed levels: bins of 4096 consecutive entries (the hash spreads any batch evenly, and the
-// slice goes back to the table in contiguous atomics).  Dense levels: entries dealt round-robin over 128 bins, so that the
-// spatially clustered updates of a ray bundle still fill the bins evenly (the slice goes back with scattered atomics -- few,
-// the tables are small).
-__device__ __forceinline__ uint32_t bin_of(uint32_t e, bool hashed) { return hashed ? e >> kBinLog : e & (kBinMax - 1); }
-__device__ __forceinline__ uint32_t slot_of(uint32_t e, bool hashed) { return hashed ? e & (kBinEntries - 1) : e >> 7; }
-__device__ __forceinline__ uint32_t entry_of(uint32_t bin, uint32_t slot, bool hashed) { return hashed ? (bin << kBinLog) + slot : (slot << 7) + bin; }
+constexpr uint32_t kBinSplit = 8;                                // reducing workgroups per bin (fewer where a bin holds little)
+constexpr uint32_t kBinSplitMin = 32768;                         // ... at least this many records each
+constexpr uint32_t kFillStride = 32;                             // one fill counter per 128-byte line
+constexpr uint32_t kBinShards = 32;                              // a bin's region is split into this many independently filled parts:
+                                                                 // atomics on ONE address complete at ~10 M/s (measured), a batch of
+                                                                 // 29.5 M points would put 28 800 on each bin's counter
+// entry -> (bin, slot in the bin): every level is dealt over all 128 bins.  Hashed levels: by 128-byte line of the table (32
+// entries), lines round-robin over the bins -- the slice goes back to the table line by line with coalesced atomics, and the bin
+// depends on bits 5-11 of the index, which the x coordinate reaches (bins of 4096 CONSECUTIVE entries depend on y and z only while
+// the resolution is below 4096: measured 1.5 x the mean load on the fullest bin, which overflows any reasonable region).  Dense
+// levels: entries round-robin, so that the spatially clustered updates of a ray bundle still fill the bins evenly (the slice
+// goes back with scattered atomics -- few, the tables are small).
+__device__ __forceinline__ uint32_t bin_of(uint32_t e, bool hashed) { return hashed ? (e >> 5) & (kBinMax - 1) : e & (kBinMax - 1); }
+__device__ __forceinline__ uint32_t slot_of(uint32_t e, bool hashed) { return hashed ? (e & 31u) | ((e >> 12) << 5) : e >> 7; }
+__device__ __forceinline__ uint32_t entry_of(uint32_t bin, uint32_t slot, bool hashed) {
+    return hashed ? ((slot >> 5) << 12) | (bin << 5) | (slot & 31u) : (slot << 7) + bin;
+}
 static_assert(kBinMax == 128, "slot_of / entry_of assume 128 bins");
-template <int D>
-__global__ void __launch_bounds__(kBinPoints) k_grid_bwd_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs,
-                                                             _Float16* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
-                                                             bool align_corners, BinLevels bl, uint32_t first, uint2* __restrict__ records,
-                                                             uint32_t* __restrict__ counts) {
-    constexpr int C = 2;
-    extern __shared__ uint2 rec[];                       // [kBinMax][kBinCap]
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(rec + kBinMax * kBinCap);
+
+// records per (bin, shard) region: an odd multiple of 32 (256 bytes).  The regions of a hashed level fill in lockstep, so at any
+// moment the workgroups write at (region * cap + the common fill level): with a stride that is a multiple of a large power of two
+// all those writes camp on one memory channel (measured: 4.1 ms per level instead of 0.7); an odd multiple of 256 bytes walks them
+// over every channel whatever the interleaving granularity.
+__host__ __device__ __forceinline__ uint32_t region_cap(size_t level_records, uint32_t n_bins) {
+    const uint32_t raw = (uint32_t)(level_records / ((size_t)n_bins * kBinShards));
+    return ((raw - 32u) / 64u) * 64u + 32u;
+}
+
+struct BinPlan {     // workspace layout of one launch group (device pointers)
+    uint2* records;  // [levels of the group][n_bins(level) regions of `cap` records]
+    uint32_t* fill;  // [levels of the group][kBinMax * kFillStride]
+    size_t level_records;   // records per level (all regions)
+};
+
+template <int D, int NT>
+__global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs,
+                                                     _Float16* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
+                                                     bool align_corners, BinLevels bl, uint32_t first, BinPlan plan) {
+    constexpr int C = 2, NC = 1 << D;
+    extern __shared__ uint2 rec[];                       // [NT * NC] records sorted by bin
+    __shared__ uint32_t cnt[kBinMax], off[kBinMax], gbase[kBinMax];
     const uint32_t level = bl.level[first + blockIdx.y];
     _Float16* tab = grad_grid + (size_t)lv.offset[level] * C;
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
     const uint32_t resolution = lv.resolution[level];
     const bool hashed = lv.hashed[level] != 0;
-    const uint32_t n_bins = hashed ? (hashmap_size + kBinEntries - 1) >> kBinLog : kBinMax;
+    const uint32_t n_bins = kBinMax;
+    const uint32_t cap = region_cap(plan.level_records, n_bins);
+    const uint32_t shard = blockIdx.x % kBinShards;
+    uint2* region = plan.records + (size_t)blockIdx.y * plan.level_records;
+    uint32_t* fill = plan.fill + ((size_t)blockIdx.y * kBinMax * kBinShards + shard) * kFillStride;
     if (threadIdx.x < kBinMax) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t b = blockIdx.x * kBinPoints + threadIdx.x;
+    const uint32_t b = blockIdx.x * NT + threadIdx.x;
     float pos[D];
     uint32_t pg[D];
     const bool valid = locate<_Float16, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
@@ -521,90 +610,142 @@ __global__ void __launch_bounds__(kBinPoints) k_grid_bwd_bin(const _Float16* __r
         const Vec<_Float16, C> gv = *reinterpret_cast<const Vec<_Float16, C>*>(grad + ((size_t)level * B + b) * C);
         g[0] = (float)gv.v[0]; g[1] = (float)gv.v[1];
     }
+    float v[NC * C];
 #pragma unroll
-    for (int idx = 0; idx < (1 << D); idx++) {
+    for (int idx = 0; idx < NC; idx++) {
         float w = 1;
-        uint32_t pl[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
-            pl[d] = pg[d] + ((idx >> d) & 1);
-        }
-        const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
-        float v[C] = {w * g[0], w * g[1]};
-        if (combine_runs<C>(e, valid, v)) {
+        for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+        v[idx * 2] = w * g[0]; v[idx * 2 + 1] = w * g[1];
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool tail = merge_cell_rows<D>(valid, pg, v);
+    uint32_t key[NC], val[NC];                            // slot | bin << 12 | rank in the bin << 19;  the two halves
+    if (tail) {
+#pragma unroll
+        for (int idx = 0; idx < NC; idx++) {
+            uint32_t pl[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
+            const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
             const uint32_t bin = bin_of(e, hashed);
             const uint32_t r = atomicAdd(&cnt[bin], 1u);
-            if (r < kBinCap) {
-                const __half2 h = __halves2half2(__float2half_rn(v[0]), __float2half_rn(v[1]));
-                rec[bin * kBinCap + r] = make_uint2(slot_of(e, hashed), *reinterpret_cast<const uint32_t*>(&h));
-            } else {
-                table_add<_Float16, C>(tab, e, v);       // bin full: straight to the table
-            }
+            // finite halves only (the reference's half atomics would carry an overflowed sum as inf; the fixed-point slice cannot)
+            const __half2 h = __halves2half2(__float2half_rn(fminf(fmaxf(v[idx * 2], -65504.0f), 65504.0f)),
+                                             __float2half_rn(fminf(fmaxf(v[idx * 2 + 1], -65504.0f), 65504.0f)));
+            key[idx] = slot_of(e, hashed) | (bin << kBinLog) | (r << 19);
+            val[idx] = *reinterpret_cast<const uint32_t*>(&h);
         }
     }
     __syncthreads();
-    const size_t seg = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBinMax;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t bin = wave; bin < n_bins; bin += kBinPoints / 64) {
-        const uint32_t c = cnt[bin] < kBinCap ? cnt[bin] : kBinCap;
-        uint2* dst = records + (seg + bin) * kBinCap;
-        for (uint32_t r = lane; r < c; r += 64) dst[r] = rec[bin * kBinCap + r];
-        if (lane == 0) counts[seg + bin] = c;
+    if (threadIdx.x < 64) {            // wave 0: exclusive scan of the 128 counts, room in the regions
+        const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
+        uint32_t g0 = 0, g1 = 0;
+        if (c0) g0 = atomicAdd(&fill[(2 * lane) * kBinShards * kFillStride], c0);
+        if (c1) g1 = atomicAdd(&fill[(2 * lane + 1) * kBinShards * kFillStride], c1);
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += up;
+        }
+        off[2 * lane] = incl - c0 - c1;
+        off[2 * lane + 1] = incl - c1;
+        gbase[2 * lane] = g0;
+        gbase[2 * lane + 1] = g1;
+    }
+    __syncthreads();
+    if (tail) {
+#pragma unroll
+        for (int idx = 0; idx < NC; idx++) {
+            const uint32_t bin = (key[idx] >> kBinLog) & (kBinMax - 1);
+            rec[off[bin] + (key[idx] >> 19)] = make_uint2(key[idx] & ((1u << 19) - 1), val[idx]);
+        }
+    }
+    __syncthreads();
+    const uint32_t total = off[kBinMax - 1] + cnt[kBinMax - 1];
+    for (uint32_t i = threadIdx.x; i < total; i += NT) {
+        const uint2 r = rec[i];
+        const uint32_t bin = r.x >> kBinLog;
+        const uint32_t at = gbase[bin] + (i - off[bin]);
+        if (at < cap) {
+            region[((size_t)bin * kBinShards + shard) * cap + at] = r;
+        } else {                                          // region full: straight to the table
+            const __half2 h = *reinterpret_cast<const __half2*>(&r.y);
+            const float vv[2] = {__low2float(h), __high2float(h)};
+            table_add<_Float16, C>(tab, entry_of(bin, r.x & (kBinEntries - 1), hashed), vv);
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) k_grid_bwd_bin_reduce(const uint2* __restrict__ records, const uint32_t* __restrict__ counts,
-                                                             _Float16* __restrict__ grad_grid, GridLevels lv, BinLevels bl, uint32_t first,
-                                                             uint32_t n_pblocks, uint32_t n_split) {
-    __shared__ float acc[kBinEntries * 2];
+// fp16 bit pattern -> the value in units of 2^-24 (the smallest fp16 subnormal): exact for every finite half, |result| < 2^40
+__device__ __forceinline__ long long half_bits_to_fixed(uint32_t hb) {
+    const uint32_t e = (hb >> 10) & 31u, m = hb & 1023u;
+    const unsigned long long mag = e ? (unsigned long long)(1024u | m) << (e - 1u) : (unsigned long long)m;
+    return (hb & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+
+// LDS accumulators are 64-bit fixed point, not floats: ds_add_f32 runs at about a tenth of the integer LDS atomics' rate on gfx950
+// (measured: 650 us against 75 us for the same 33 M records), and the integer sum of fp16 values is exact, so the slice does not
+// depend on the order the records arrive in.
+constexpr uint32_t kReduceThreads = 512;
+__global__ void __launch_bounds__(kReduceThreads) k_grid_bwd_bin_reduce(_Float16* __restrict__ grad_grid, GridLevels lv, BinLevels bl,
+                                                                        uint32_t first, BinPlan plan) {
+    extern __shared__ unsigned long long acc64[];        // [kBinEntries * 2]
+    __shared__ uint32_t fills[kBinShards];
     const uint32_t level = bl.level[first + blockIdx.y];
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
     const bool hashed = lv.hashed[level] != 0;
-    const uint32_t n_bins = hashed ? (hashmap_size + kBinEntries - 1) >> kBinLog : kBinMax;
-    const uint32_t bin = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const uint32_t n_bins = kBinMax;
+    const uint32_t bin = blockIdx.x / kBinSplit, split = blockIdx.x % kBinSplit;
     if (bin >= n_bins) return;
-    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += 256) acc[i] = 0.0f;
+    const uint32_t cap = region_cap(plan.level_records, n_bins);
+    const uint32_t* fill = plan.fill + ((size_t)blockIdx.y * kBinMax + bin) * kBinShards * kFillStride;
+    if (threadIdx.x < kBinShards) {
+        const uint32_t n = fill[threadIdx.x * kFillStride];
+        fills[threadIdx.x] = n < cap ? n : cap;
+    }
+    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += kReduceThreads) acc64[i] = 0ull;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // each wave walks its share of the point blocks, four segments in flight; a segment's records are loaded without waiting for
-    // its count (slots past the count hold stale bytes and are masked)
-    constexpr uint32_t U = 4;
-    const uint32_t stride = n_split * 4;
-    for (uint32_t blk0 = split * 4 + wave; blk0 < n_pblocks; blk0 += stride * U) {
-        uint32_t c[U];
-        uint2 u0[U];
-        const uint2* src[U];
+    uint32_t total = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < U; k++) {
-            const uint32_t blk = blk0 + k * stride;
-            const bool on = blk < n_pblocks;
-            const size_t seg = ((size_t)blockIdx.y * n_pblocks + (on ? blk : 0)) * kBinMax + bin;
-            c[k] = on ? counts[seg] : 0u;
-            src[k] = records + seg * kBinCap;
-            u0[k] = src[k][lane];
-        }
+    for (uint32_t k = 0; k < kBinShards; k++) total += fills[k];
+    // reducing workgroups of this bin: a power of two, each at least kBinSplitMin records (zeroing and flushing a slice is not free)
+    uint32_t n_split = 1;
+    while (n_split < kBinSplit && total >= 2 * n_split * kBinSplitMin) n_split *= 2;
+    if (split >= n_split || total == 0) return;
+    const uint2* base = plan.records + (size_t)blockIdx.y * plan.level_records + (size_t)bin * kBinShards * cap;
+    auto add = [&](uint32_t key, uint32_t val) {
+        const uint32_t slot = key & (kBinEntries - 1);
+        atomicAdd(&acc64[slot * 2], (unsigned long long)half_bits_to_fixed(val & 0xffffu));
+        atomicAdd(&acc64[slot * 2 + 1], (unsigned long long)half_bits_to_fixed(val >> 16));
+    };
+    constexpr uint32_t U = 4, kStep = 2 * kReduceThreads;
+    for (uint32_t sh = split; sh < kBinShards; sh += n_split) {
+        const uint32_t end = fills[sh];
+        const uint4* src = reinterpret_cast<const uint4*>(base + (size_t)sh * cap);
+        for (uint32_t i0 = 2 * threadIdx.x; i0 < end; i0 += kStep * U) {
+            uint4 q[U];
 #pragma unroll
-        for (uint32_t k = 0; k < U; k++) {
-            if (lane < c[k]) {
-                const __half2 h = *reinterpret_cast<const __half2*>(&u0[k].y);
-                atomicAdd(&acc[u0[k].x * 2], __low2float(h));
-                atomicAdd(&acc[u0[k].x * 2 + 1], __high2float(h));
+            for (uint32_t k = 0; k < U; k++) {
+                const uint32_t i = i0 + k * kStep;
+                q[k] = i < end ? src[i >> 1] : make_uint4(0, 0, 0, 0);
             }
-            if (lane + 64 < c[k]) {      // the segment's tail (only the fuller half of the segments have one)
-                const uint2 u1 = src[k][lane + 64];
-                const __half2 h = *reinterpret_cast<const __half2*>(&u1.y);
-                atomicAdd(&acc[u1.x * 2], __low2float(h));
-                atomicAdd(&acc[u1.x * 2 + 1], __high2float(h));
+#pragma unroll
+            for (uint32_t k = 0; k < U; k++) {
+                const uint32_t i = i0 + k * kStep;
+                if (i < end) add(q[k].x, q[k].y);
+                if (i + 1 < end) add(q[k].z, q[k].w);
             }
         }
     }
     __syncthreads();
     _Float16* tab = grad_grid + (size_t)lv.offset[level] * 2;
-    for (uint32_t i = threadIdx.x; i < kBinEntries; i += 256) {
+    for (uint32_t i = threadIdx.x; i < kBinEntries; i += kReduceThreads) {
         const uint32_t e = entry_of(bin, i, hashed);
-        const float v[2] = {acc[i * 2], acc[i * 2 + 1]};
-        if (e < hashmap_size && (v[0] != 0.0f || v[1] != 0.0f)) table_add<_Float16, 2>(tab, e, v);
+        const long long a0 = (long long)acc64[i * 2], a1 = (long long)acc64[i * 2 + 1];
+        const float v[2] = {(float)a0 * 0x1p-24f, (float)a1 * 0x1p-24f};
+        if (e < hashmap_size && (a0 != 0 || a1 != 0)) table_add<_Float16, 2>(tab, e, v);
     }
 }
 
@@ -618,6 +759,18 @@ static bool g4_off() {                                   // diagnostics (NGP_GRI
 static bool bin_off() {                                  // diagnostics (NGP_GRID_NO_BINS set): atomics for every level
     static const bool off = getenv("NGP_GRID_NO_BINS") != nullptr;
     return off;
+}
+
+// records one level's regions hold: 1.5 x the 2^D updates per point of a batch without mergeable neighbours, + slack for tiny batches
+// (diagnostics: NGP_GRID_BIN_FILL_PCT=<percent of the updates the regions hold> shrinks them so that ordinary inputs overflow)
+static size_t bin_level_records(uint32_t B, uint32_t corners) {
+    constexpr size_t parts = 2 * kBinMax * kBinShards;
+    const char* env = getenv("NGP_GRID_BIN_FILL_PCT");
+    const size_t pct = env && atoi(env) > 0 ? (size_t)atoi(env) : 150;
+    return (((size_t)B * corners * pct / 100 + kBinMax * kBinShards * 128) / parts) * parts;
+}
+static size_t bin_level_bytes(uint32_t B, uint32_t corners) {
+    return bin_level_records(B, corners) * sizeof(uint2) + (size_t)kBinMax * kBinShards * kFillStride * sizeof(uint32_t);
 }
 
 // :317-343
@@ -698,12 +851,12 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         if (floats <= kSmallMaxFloats && (size_t)B * 8 >= (size_t)floats * 16) {
             small_mask |= 1u << l;
             n_small++;
-            lds = lds > floats * sizeof(float) ? lds : floats * sizeof(float);
+            lds = lds > floats * sizeof(unsigned long long) ? lds : floats * sizeof(unsigned long long);
         }
     }
     if (n_small) {
         auto kern = k_grid_backward_small<T, D, C>;
-        ensure_dynamic_lds((const void*)kern, (int)(kSmallMaxFloats * sizeof(float)));
+        ensure_dynamic_lds((const void*)kern, (int)(kSmallMaxFloats * sizeof(unsigned long long)));
         const uint32_t n_pb = div_up(B, (uint32_t)kSmallThreads);
         const uint32_t bx = n_pb < 256u ? n_pb : 256u;
         kern<<<dim3(bx, n_small), kSmallThreads, lds, s>>>((const T*)grad, inputs, (T*)grad_emb, B, lv, gridtype, ac, small_mask);
@@ -716,25 +869,48 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         if (!bin_off() && B >= 128u * 1024u)
             for (uint32_t l = 0; l < L; l++)
                 if (!((small_mask >> l) & 1u) && lv.offset[l + 1] - lv.offset[l] <= kBinMax * kBinEntries) bl.level[n_bin++] = l;
-        const uint32_t n_pb = div_up(B, kBinPoints);
-        const size_t per_level = (size_t)n_pb * kBinMax * (kBinCap * sizeof(uint2) + sizeof(uint32_t));
+        const size_t level_records = bin_level_records(B, 1u << D);
+        const size_t per_level = bin_level_bytes(B, 1u << D);
         const size_t usable = workspace ? (workspace_bytes < kBinWorkspaceMax ? workspace_bytes : kBinWorkspaceMax) : 0;
         uint32_t group = n_bin ? (uint32_t)(usable / per_level) : 0;
         group = group < n_bin ? group : n_bin;
         char* ws = group ? (char*)workspace : nullptr;
         if (ws) {
-            const size_t lds_bin = (size_t)kBinMax * kBinCap * sizeof(uint2) + kBinMax * sizeof(uint32_t);
-            ensure_dynamic_lds((const void*)k_grid_bwd_bin<D>, (int)lds_bin);
-            uint2* records = reinterpret_cast<uint2*>(ws);
-            uint32_t* counts = reinterpret_cast<uint32_t*>(ws + (size_t)group * n_pb * kBinMax * kBinCap * sizeof(uint2));
+            constexpr uint32_t NT = 1024;
+            const uint32_t n_pb = div_up(B, NT);
+            const size_t lds_bin = (size_t)NT * (1u << D) * sizeof(uint2);
+            ensure_dynamic_lds((const void*)k_grid_bwd_bin<D, NT>, (int)lds_bin);
+            const size_t lds_red = (size_t)kBinEntries * 2 * sizeof(unsigned long long);
+            ensure_dynamic_lds((const void*)k_grid_bwd_bin_reduce, (int)lds_red);
+            BinPlan plan;
+            plan.records = reinterpret_cast<uint2*>(ws);
+            plan.fill = reinterpret_cast<uint32_t*>(ws + (size_t)group * level_records * sizeof(uint2));
+            plan.level_records = level_records;
             for (uint32_t first = 0; first < n_bin; first += group) {
                 const uint32_t n = n_bin - first < group ? n_bin - first : group;
-                k_grid_bwd_bin<D><<<dim3(n_pb, n), kBinPoints, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype, ac, bl,
-                                                                              first, records, counts);
-                // reducing workgroups per bin: one per ~64 point blocks (each zeroes and flushes a 32 KB slice: not worth it for less)
-                uint32_t n_split = n_pb / 64;
-                n_split = n_split < 1 ? 1 : (n_split > kBinSplit ? kBinSplit : n_split);
-                k_grid_bwd_bin_reduce<<<dim3(kBinMax * n_split, n), 256, 0, s>>>(records, counts, (_Float16*)grad_emb, lv, bl, first, n_pb, n_split);
+                (void)hipMemsetAsync(plan.fill, 0, (size_t)n * kBinMax * kBinShards * kFillStride * sizeof(uint32_t), s);
+                k_grid_bwd_bin<D, NT><<<dim3(n_pb, n), NT, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype, ac, bl,
+                                                                          first, plan);
+                k_grid_bwd_bin_reduce<<<dim3(kBinMax * kBinSplit, n), kReduceThreads, lds_red, s>>>((_Float16*)grad_emb, lv, bl, first, plan);
+                if (getenv("NGP_GRID_BWD_STATS")) {      // diagnostics: how evenly the regions filled
+                    std::vector<uint32_t> h((size_t)n * kBinMax * kBinShards * kFillStride);
+                    (void)hipStreamSynchronize(s);
+                    (void)hipMemcpy(h.data(), plan.fill, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                    for (uint32_t i = 0; i < n; i++) {
+                        const uint32_t level = bl.level[first + i];
+                        const uint32_t hs = lv.offset[level + 1] - lv.offset[level];
+                        const uint32_t nb = kBinMax; (void)hs;
+                        const uint32_t cap = region_cap(level_records, nb);
+                        uint64_t tot = 0, over = 0; uint32_t mx = 0;
+                        for (uint32_t r = 0; r < nb * kBinShards; r++) {
+                            const uint32_t f = h[((size_t)i * kBinMax * kBinShards + r) * kFillStride];
+                            tot += f; mx = f > mx ? f : mx; over += f > cap ? f - cap : 0;
+                        }
+                        fprintf(stderr, "[grid bwd] level %u res %u hashed %d: records %llu (%.2f per point) max region %u cap %u mean %.0f overflow %llu\n", level,
+                                lv.resolution[level], (int)lv.hashed[level], (unsigned long long)tot, (double)tot / B, mx, cap, (double)tot / (nb * kBinShards),
+                                (unsigned long long)over);
+                    }
+                }
             }
             for (uint32_t i = 0; i < n_bin; i++) done_mask |= 1u << bl.level[i];
             n_done += n_bin;
@@ -854,9 +1030,8 @@ int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* 
 
 size_t ngp_grid_encode_backward_workspace(uint32_t B, uint32_t D, uint32_t C, uint32_t L, int dtype) {
     // only the binned scatter of an fp16, two-feature table on a large batch uses it (launch_backward)
-    (void)D;
     if (dtype != NGP_F16 || C != 2 || B < 128u * 1024u || bin_off()) return 0;
-    const size_t per_level = (size_t)div_up(B, kBinPoints) * kBinMax * (kBinCap * sizeof(uint2) + sizeof(uint32_t));
+    const size_t per_level = bin_level_bytes(B, 1u << D);
     const size_t all = per_level * L;
     if (all <= kBinWorkspaceMax) return all;
     const size_t group = kBinWorkspaceMax / per_level;

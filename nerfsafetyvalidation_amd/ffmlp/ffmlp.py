@@ -46,10 +46,12 @@ class _ffmlp_forward(Function):
         grad = grad.contiguous()
         inputs, weights, outputs, forward_buffer = ctx.saved_tensors
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
-        grad_inputs = torch.zeros_like(inputs) if calc_grad_inputs else None
-        grad_weights = torch.zeros_like(weights)
-        backward_buffer = torch.zeros(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         lib = _lib.lib()
+        # every row / parameter is written by the call; the activation gradients only go to memory for shapes that need them there
+        grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else None
+        grad_weights = torch.empty_like(weights)
+        bbytes = lib.ngp_ffmlp_backward_buffer_bytes(B, input_dim, hidden_dim, num_layers)
+        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype) if bbytes else None
         # split-K partials of the weight gradients: this call's own scratch from torch's (stream-aware) caching allocator, so
         # backward passes running concurrently on other streams never share it
         wbytes = lib.ngp_ffmlp_backward_workspace(B, input_dim, hidden_dim, num_layers)

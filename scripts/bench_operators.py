@@ -78,10 +78,10 @@ line("ffmlp_forward, training (sigma 32-64-64-16 and colour 32-64-64-64-16, aver
      note="bytes: 64 in + 32 out + the stored hidden activations (2 or 3 x 128 B per row) that the backward pass reads")
 line("composite_rays_train_forward", "composite_rays_train_forward", M, "samples", 24 * M + (12 + 20) * N)
 line("composite_rays_train_backward", "composite_rays_train_backward", M, "samples", (24 + 16) * M + (12 + 4 + 12 + 4 + 12) * N)
-line("ffmlp_backward (both nets, averaged: activation chain + split-K weight gradients)", "ffmlp_backward", Mp, "rows",
-     (32 + 64 + 2.5 * 128 * 2 + 64 + 2.5 * 128 * 2 + 32) * Mp, flops_per_call=2 * (14336 + 22528) / 2 * Mp,
-     note="bytes: chain reads grad 32 + stored activations, writes activation gradients + input gradient 64; weight-gradient pass reads "
-          "inputs 64, activations and activation gradients again, grad 32")
+line("ffmlp_backward (both nets, averaged: activation + weight gradients in one pass, fixed-order reduction of the partials)", "ffmlp_backward", Mp, "rows",
+     (32 + 2.5 * 128 + 64 + 64) * Mp, flops_per_call=2 * (14336 + 22528) / 2 * Mp,
+     note="bytes: grad 32 + the stored activations (2 or 3 x 128 B per row) + inputs 64 + the input gradient 64; round 1's two-kernel form "
+          "moved 1472 B per row (activation gradients written and read back, activations read twice) and its table priced those")
 # (sh_encode_backward is not launched by a training step -- view directions carry no gradient there -- it is timed below, on
 #  the pose-gradient shape where it does run)
 line("grid_encode_backward f16 (table gradient, packed-half atomics)", "grid_encode_backward", Mp, "points", 588 * Mp)

@@ -266,12 +266,16 @@ def test_grid_encode_forward_bit_exact(device, dtype, D, C):
                                    **(dict(rtol=1e-4, atol=1e-5) if dtype == np.float32 else dict(rtol=5e-2, atol=5e-2)))
 
 
-@pytest.mark.parametrize("dtype,n_rays,T", [(np.float32, 600, 100), (np.float16, 600, 100), (np.float16, 600, 260), (np.float16, 160000, 1)])
-def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T):
-    """Table gradient on a batch in ray order (consecutive points share cells at the coarse levels: the wave-level run combining)
+@pytest.mark.parametrize("dtype,n_rays,T,fill_pct", [(np.float32, 600, 100, None), (np.float16, 600, 100, None), (np.float16, 600, 260, None),
+                                                     (np.float16, 160000, 1, None), (np.float16, 600, 260, 60), (np.float16, 160000, 1, 20)])
+def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_pct, monkeypatch):
+    """Table gradient on a batch in ray order (consecutive points share cells at the coarse levels: the row-level run combining)
     and large enough for the LDS-accumulated levels, against the oracle's scatter; a frozen table gets no gradient and the input
-    gradient is unchanged by that."""
+    gradient is unchanged by that.  fill_pct: the regions of the binned scatter sized for that share of the updates only, so that
+    part of them takes the overflow route (straight to the table)."""
     from nerfsafetyvalidation_amd.gridencoder import grid_encode
+    if fill_pct is not None:
+        monkeypatch.setenv("NGP_GRID_BIN_FILL_PCT", str(fill_pct))
     rng = np.random.default_rng(11)
     D, C, L = 3, 2, 16
     offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=19, desired_resolution=2048)
@@ -433,6 +437,14 @@ def test_ffmlp_backward_buffers_direct(device):
         np.testing.assert_allclose(gi, wi, rtol=4e-3, atol=2e-3)
         np.testing.assert_allclose(gw, ww, rtol=4e-3, atol=2e-3 * np.abs(ww).max())
         assert (gw == ww).mean() > 0.9
+    # the activation gradients need not go to memory for this shape: backward_buffer may be NULL, nothing else changes
+    assert lib.ngp_ffmlp_backward_buffer_bytes(B, nin, hid, nl) == 0 and lib.ngp_ffmlp_backward_buffer_bytes(B, nin, 128, nl) == nl * B * 128 * 2
+    keep_gi, keep_gw = got[1].clone(), got[2].clone()
+    got[1].fill_(7.0); got[2].fill_(7.0)
+    _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6, 1,
+                                      None, _lib.ptr(got[1]), _lib.ptr(got[2]), _lib.ptr(work), wbytes, _lib.stream()), "ffmlp_backward")
+    assert torch.equal(got[2], keep_gw)
+    np.testing.assert_allclose(got[1].float().cpu().numpy(), want[1].astype(np.float32), rtol=4e-3, atol=2e-3)
     # determinism of the split-K reduction: two calls, identical bits
     first = got[2].clone()
     _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), B, nin, 16, hid, nl, 0, 6, 0,
