@@ -298,6 +298,16 @@ NGP_API int ngp_render_uniform(const ngp_model* model, const float* rays_o, cons
                        float* image, float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs,
                        ngp_stream_t stream);
 
+/* The same with the NeRF-style importance resampling of nerf/renderer.py:172-204 in evaluation mode (sample_pdf :12-46 with det=True):
+ * T uniform samples, U more drawn from the piecewise-constant PDF of the coarse weights (u = the U values of
+ * torch.linspace(0.5 / U, 1 - 0.5 / U, U), device memory), both runs merged in depth order and composited together.  Outputs as
+ * ngp_render_uniform, with T + U samples per ray in the optional sigmas / rgbs.  T >= 3; (5 T + 4 U) floats of LDS per ray must fit
+ * beside the weights (T = U = 1024 does; the call refuses what does not). */
+NGP_API int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears,
+                        const float* fars, uint32_t N, uint32_t T, uint32_t U, const float* lin, const float* u,
+                        float* weights_sum, float* depth, float* image, float* aggregated_density, uint32_t dump_begin,
+                        float* sigmas, float* rgbs, ngp_stream_t stream);
+
 /* Vector-Jacobian product of ngp_render_uniform with respect to the RAYS with the map (table, weights) frozen: what
  * nav/estimator_helpers.py:191-225 differentiates (pose gradients through get_rays -> render -> run, <= 1024 pixels x 512 samples).
  * One launch, nothing saved by the forward call: grad_image [N,3] (of the image BEFORE the background mix), grad_depth /

@@ -568,16 +568,21 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
             lrow[t] = ((wave * TPW + t) * 16 + c) * SH;
         }
         // ---- output matrix: dH_last^T = W_out^T * grad^T; dW_out = grad^T * fwd[L-1] ----
+        // every operand of the group in flight at once: one exposed memory latency per group instead of one per matrix
+        half4 gB[TPW], fa[L][TPW][HB], xin[TPW][HB];
+#pragma unroll
+        for (int t = 0; t < (int)TPW; t++) {
+            gB[t] = ld_half4(grad + row[t] * 16 + g * 4);
+#pragma unroll
+            for (int l = (int)L - 1; l >= 0; l--)
+#pragma unroll
+                for (int ib = 0; ib < HB; ib++) fa[l][t][ib] = ld_half4(fwd + (size_t)l * BH + row[t] * HID + ib * 16 + g * 4);
+#pragma unroll
+            for (int ib = 0; ib < HB; ib++) xin[t][ib] = ib < (int)IB ? ld_half4(inputs + row[t] * in_dim + ib * 16 + g * 4) : zero4;
+        }
         half4 dh[TPW][HB];
         {
-            half4 gB[TPW], fl[TPW][HB];
-            const _Float16* f = fwd + (size_t)(L - 1) * BH;
-#pragma unroll
-            for (int t = 0; t < (int)TPW; t++) {
-                gB[t] = ld_half4(grad + row[t] * 16 + g * 4);
-#pragma unroll
-                for (int ib = 0; ib < HB; ib++) fl[t][ib] = ld_half4(f + row[t] * HID + ib * 16 + g * 4);
-            }
+            half4 (&fl)[TPW][HB] = fa[L - 1];
 #pragma unroll
             for (int t = 0; t < (int)TPW; t++) {
                 st_half4(Gt + lrow[t] + g * 4, valid[t] ? gB[t] : zero4);
@@ -604,15 +609,9 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
         // ---- hidden matrices, last to first: dW_hid[m] = dH_{m+1}^T * fwd[m]; dH_m^T = W_hid[m]^T * dH_{m+1}^T ----
 #pragma unroll
         for (int k = 0; k < NL; k++) {
-            constexpr int dummy = 0; (void)dummy;
             const int m = NL - 1 - k;
             const _Float16* Wl = lds + off_hid + m * HID * SH;
-            const _Float16* f = fwd + (size_t)m * BH;
-            half4 fm[TPW][HB];
-#pragma unroll
-            for (int t = 0; t < (int)TPW; t++)
-#pragma unroll
-                for (int ib = 0; ib < HB; ib++) fm[t][ib] = ld_half4(f + row[t] * HID + ib * 16 + g * 4);
+            half4 (&fm)[TPW][HB] = fa[m];
 #pragma unroll
             for (int t = 0; t < (int)TPW; t++)
 #pragma unroll
@@ -658,10 +657,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
 #pragma unroll
             for (int ib = 0; ib < HB; ib++) {
                 st_half4(Gt + lrow[t] + ib * 16 + g * 4, valid[t] ? dh[t][ib] : zero4);
-                if (ib < (int)IB) {
-                    const half4 x = ld_half4(inputs + row[t] * in_dim + ib * 16 + g * 4);
-                    st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? x : zero4);
-                }
+                if (ib < (int)IB) st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? xin[t][ib] : zero4);
             }
         __syncthreads();
 #pragma unroll

@@ -689,6 +689,202 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// NeRFRenderer.run WITH the NeRF-style importance resampling (nerf/renderer.py:172-204, sample_pdf :12-46), evaluation mode
+// (`det`: the u of the inverse-CDF draw are the fixed linspace of :26).  One wave walks one ray; everything the reference keeps
+// in [N, T, *] / [N, T + U, *] tensors -- coarse depths and densities, their weights, the CDF, the U resampled depths, the
+// merged order -- lives in a few KB of LDS per wave:
+//   1. coarse pass: T uniform samples, fused hash grid + sigma net                                   (:148-170)
+//   2. weights of the coarse samples (:176-180), CDF over the T - 1 mid points of weights[1:-1] + 1e-5 (:17-22), U inverse-CDF
+//      samples by binary search (:29-44)
+//   3. fine pass: sigma at the U new depths                                                          (:181-184)
+//   4. merge of the two ascending runs (the sort + gathers of :187-193; coarse first on ties)
+//   5. compositing over the T + U merged samples exactly as k_render_uniform does; a tile that holds a sample with weight > 1e-4
+//      re-evaluates the sigma net for its geometry features (bit-identical to the first evaluation) and runs the colour net.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) k_render_upsample(NetArgs na, GridLevels lv, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                         const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N, uint32_t T,
+                                                         uint32_t U, const float* __restrict__ lin, const float* __restrict__ u_det,
+                                                         float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
+                                                         float* __restrict__ aggregated_density, uint32_t dump_begin, float* __restrict__ sigmas,
+                                                         float* __restrict__ rgbs, float aabb_lo, float aabb_hi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const uint32_t Tm = T + U;
+    float* zc = reinterpret_cast<float*>(smem + w_bytes + sizeof(LevelTab)) + (size_t)wid * (5 * T + 4 * U);
+    float* sc = zc + T;
+    float* cdf = sc + T;          // first the coarse weights, then (in place) the CDF
+    float* zf = cdf + T;
+    float* sf = zf + U;
+    float* zm = sf + U;
+    float* sm = zm + Tm;
+#define NGP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    for (uint32_t ray = blockIdx.x * wpb + wid; ray < N; ray += gridDim.x * wpb) {
+        const float ox = rays_o[(size_t)ray * 3], oy = rays_o[(size_t)ray * 3 + 1], oz = rays_o[(size_t)ray * 3 + 2];
+        const float dx = rays_d[(size_t)ray * 3], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
+        const float near = nears[ray], far = fars[ray];
+        const float span = far - near;
+        const float sample_dist = span * (1.0f / (float)T);                          // :153
+        const bool dump = sigmas != nullptr && ray >= dump_begin;
+        // ---- 1. / 3. sigma along the ray: the T uniform depths, then (after the resampling below) the U new ones
+        for (int phase = 0; phase < 2; phase++) {
+            const uint32_t n = phase ? U : T;
+            float* zdst = phase ? zf : zc;
+            float* sdst = phase ? sf : sc;
+            for (uint32_t i0 = 0; i0 < n; i0 += 16) {
+                const uint32_t idx = i0 + c;
+                const bool valid = idx < n;
+                const uint32_t ii = valid ? idx : n - 1;
+                const float zv = phase ? zf[ii] : near + span * lin[ii];             // :150
+                const float x = clampf(ox + dx * zv, aabb_lo, aabb_hi);              // :159-160, :181-182
+                const float y = clampf(oy + dy * zv, aabb_lo, aabb_hi);
+                const float z = clampf(oz + dz * zv, aabb_lo, aabb_hi);
+                float sigma;
+                _Float16 s16[4];
+                net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+                if (lane < 16 && valid) { zdst[idx] = zv; sdst[idx] = sigma; }
+            }
+            NGP_WAVE_SYNC();
+            if (phase) break;
+            // ---- 2. coarse weights (:176-180), lane = sample
+            float carry = 1.0f;
+            for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                const bool on = t < T;
+                const uint32_t tt = on ? t : T - 1;
+                const float delta = tt + 1 < T ? zc[tt + 1] - zc[tt] : sample_dist;
+                const float alpha = on ? 1.0f - expf(((-delta) * na.density_scale) * sc[tt]) : 0.0f;
+                float incl = on ? (1.0f - alpha) + 1e-15f : 1.0f;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float o = __shfl_up(incl, off, 64);
+                    if (lane >= (uint32_t)off) incl *= o;
+                }
+                const float excl = __shfl_up(incl, 1, 64);
+                if (on) cdf[t] = alpha * (carry * (lane == 0 ? 1.0f : excl));
+                carry *= __shfl(incl, 63, 64);
+            }
+            NGP_WAVE_SYNC();
+            // sample_pdf(bins = mid points [T - 1], weights[1:-1] [T - 2]) (:12-46): cdf[k], k = 0 .. T - 2, in place of weights[k]
+            const uint32_t Tb = T - 1, Tw = T - 2;
+            float sum = 0.0f;
+            for (uint32_t t = lane; t < Tw; t += 64) sum += cdf[t + 1] + 1e-5f;      // :19-20
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            float run = 0.0f;
+            for (uint32_t t0 = 0; t0 < Tw; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                const float pdf = t < Tw ? (cdf[t + 1] + 1e-5f) / sum : 0.0f;
+                float incl = pdf;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float o = __shfl_up(incl, off, 64);
+                    if (lane >= (uint32_t)off) incl += o;
+                }
+                if (t < Tw) cdf[t + 1] = run + incl;                                 // :21
+                run += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) cdf[0] = 0.0f;                                            // :22
+            NGP_WAVE_SYNC();
+            for (uint32_t sI = lane; sI < U; sI += 64) {
+                const float us = u_det[sI];
+                uint32_t lo = 0, hi = Tb;                                            // searchsorted(cdf, u, right=True)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (cdf[mid] > us) hi = mid; else lo = mid + 1;
+                }
+                const uint32_t below = lo > 0 ? lo - 1 : 0, above = lo < Tb - 1 ? lo : Tb - 1;   // :33-34
+                float denom = cdf[above] - cdf[below];                               // :41
+                if (denom < 1e-5f) denom = 1.0f;                                     // :42
+                const float tq = (us - cdf[below]) / denom;                          // :43
+                const float b0 = zc[below] + 0.5f * (zc[below + 1] - zc[below]);     // :174 mid points
+                const float b1 = zc[above] + 0.5f * (zc[above + 1] - zc[above]);
+                zf[sI] = b0 + tq * (b1 - b0);                                        // :44
+            }
+            NGP_WAVE_SYNC();
+        }
+        // ---- 4. merge: rank of every element in the other run (coarse first on ties)
+        for (uint32_t k = lane; k < Tm; k += 64) {
+            float v, sg;
+            uint32_t pos;
+            if (k < T) {
+                v = zc[k]; sg = sc[k];
+                uint32_t lo = 0, hi = U;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (zf[mid] < v) lo = mid + 1; else hi = mid; }
+                pos = k + lo;
+            } else {
+                v = zf[k - T]; sg = sf[k - T];
+                uint32_t lo = 0, hi = T;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (zc[mid] <= v) lo = mid + 1; else hi = mid; }
+                pos = (k - T) + lo;
+            }
+            zm[pos] = v; sm[pos] = sg;
+        }
+        NGP_WAVE_SYNC();
+        // ---- 5. compositing over the merged samples (:206-244)
+        float carry = 1.0f;
+        float a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;
+        for (uint32_t i0 = 0; i0 < Tm; i0 += 16) {
+            const uint32_t idx = i0 + c;
+            const bool valid = idx < Tm;
+            const uint32_t ii = valid ? idx : Tm - 1;
+            const float zv = zm[ii], sigma = sm[ii];
+            const float delta = (ii + 1 < Tm) ? zm[ii + 1] - zv : sample_dist;       // :206-207
+            const float alpha = valid ? 1.0f - expf(((-delta) * na.density_scale) * sigma) : 0.0f;
+            float incl = (1.0f - alpha) + 1e-15f;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float o = __shfl_up(incl, off, 16);
+                if (c >= (uint32_t)off) incl *= o;
+            }
+            const float excl_in_tile = __shfl_up(incl, 1, 16);
+            const float w = alpha * (carry * (c == 0 ? 1.0f : excl_in_tile));        // :210
+            const bool masked = valid && w > 1e-4f;                                  // :216
+            float cr = 0, cg = 0, cb = 0;
+            if (__ballot(masked) != 0ull) {
+                const float x = clampf(ox + dx * zv, aabb_lo, aabb_hi);
+                const float y = clampf(oy + dy * zv, aabb_lo, aabb_hi);
+                const float z = clampf(oz + dz * zv, aabb_lo, aabb_hi);
+                float s_again;
+                _Float16 s16[4];
+                net_density<MODE>(na, Wlds, *lt, lane, x, y, z, s_again, s16);
+                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                if (!masked) { cr = 0; cg = 0; cb = 0; }
+            }
+            if (lane < 16 && valid) {
+                a_ws += w;
+                const float qz = (zv - near) / span;                                 // :227
+                a_dep += w * (qz != qz ? qz : fminf(1.0f, fmaxf(0.0f, qz)));
+                a_r += w * cr; a_g += w * cg; a_b += w * cb;
+                a_agg += w * sigma;
+                if (dump) {
+                    const size_t row = (size_t)(ray - dump_begin) * Tm + idx;
+                    sigmas[row] = sigma;
+                    rgbs[row * 3] = cr; rgbs[row * 3 + 1] = cg; rgbs[row * 3 + 2] = cb;
+                }
+            }
+            carry = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(carry * __shfl(incl, 15, 16))));
+            if (!dump && carry < 1e-10f) break;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            a_ws += __shfl_xor(a_ws, off, 16); a_dep += __shfl_xor(a_dep, off, 16); a_agg += __shfl_xor(a_agg, off, 16);
+            a_r += __shfl_xor(a_r, off, 16); a_g += __shfl_xor(a_g, off, 16); a_b += __shfl_xor(a_b, off, 16);
+        }
+        if (lane == 0) {
+            weights_sum[ray] = a_ws; depth[ray] = a_dep; aggregated_density[ray] = a_agg;
+            image[(size_t)ray * 3] = a_r; image[(size_t)ray * 3 + 1] = a_g; image[(size_t)ray * 3 + 2] = a_b;
+        }
+        NGP_WAVE_SYNC();      // the next ray overwrites the arrays
+    }
+#undef NGP_WAVE_SYNC
+}
+
 // ==========================================================================================
 // Differentiable `run`: the vector-Jacobian product of k_render_uniform with respect to the RAYS, map frozen.
 // What nav/estimator_helpers.py:191-225 (measurement_fn) differentiates -- <= 1024 chosen pixels x 512 samples, 100 Adam steps per
@@ -2310,6 +2506,44 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
         k_render_uniform<0><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
                                                      dump_begin, sigmas, rgbs, -model->bound, model->bound);
     return check_launch("render_uniform");
+}
+
+int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N,
+                        uint32_t T, uint32_t U, const float* lin, const float* u, float* weights_sum, float* depth, float* image,
+                        float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && nears && fars && lin && u && weights_sum && depth && image && aggregated_density, "render_upsample: null pointer");
+    NGP_REQUIRE((sigmas == nullptr) == (rgbs == nullptr), "render_upsample: sigmas and rgbs must both be given or both NULL");
+    NGP_REQUIRE(T >= 3 && U >= 1, "render_upsample: num_steps >= 3 and upsample_steps >= 1 (got %u, %u)", T, U);
+    hipStream_t s = (hipStream_t)stream;
+    NGP_REQUIRE(model && model->packed_weights, "render_upsample: model->packed_weights is NULL (ngp_pack_weights fills it)");
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
+    if (rc) return rc;
+    const size_t fixed = weights_bytes(na) + sizeof(LevelTab), per_wave = ((size_t)5 * T + (size_t)4 * U) * sizeof(float);
+    const size_t budget = 160 * 1024 - 1024;
+    NGP_REQUIRE(fixed + per_wave <= budget, "render_upsample: num_steps %u + upsample_steps %u need %zu bytes of LDS per ray, %zu are available", T, U,
+                per_wave, budget - fixed);
+    uint32_t waves = (uint32_t)((budget - fixed) / per_wave);
+    waves = waves > 4 ? 4 : waves;
+    const size_t lds = fixed + waves * per_wave;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_upsample<0>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_upsample<1>), 160 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_upsample<2>), 160 * 1024);
+    uint32_t blocks = div_up(N, waves);
+    if (blocks > 1024) blocks = 1024;
+    ProfScope prof("render_upsample", s, (double)N * (T + U));
+    if (needs_generic(lv))
+        k_render_upsample<1><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
+                                                             aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    else if (na.cells)
+        k_render_upsample<2><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
+                                                             aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    else
+        k_render_upsample<0><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
+                                                             aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    return check_launch("render_upsample");
 }
 
 size_t ngp_packed_weights_bwd_bytes(void) { return (size_t)(bwd_halfs(2) + bwd_halfs(3)) * 2; }

@@ -336,7 +336,7 @@ class NeRFRenderer(nn.Module):
             self._aabb_key, self._aabb_cube = key, aabb.tolist() == [-self.bound] * 3 + [self.bound] * 3
         return self._aabb_cube
 
-    def _render_staged_fused(self, fm, rays_o, rays_d, max_ray_batch, num_steps=128, bg_color=None, **kwargs):
+    def _render_staged_fused(self, fm, rays_o, rays_d, max_ray_batch, num_steps=128, upsample_steps=0, bg_color=None, **kwargs):
         """staged render through `run` for the whole frame in ONE fused launch (ngp_render_uniform); same result dict as the chunk
         loop below, including the last-chunk-only rgbs / sigmas (F8).  Differentiable in the rays (one more launch,
         ngp_render_uniform_backward): the network is treated as frozen here -- the caller checks that."""
@@ -349,7 +349,10 @@ class NeRFRenderer(nn.Module):
             with torch.no_grad():
                 nears, fars = raymarching.near_far_from_aabb(o, d, aabb, self.min_near)
             last_begin = ((N - 1) // max_ray_batch) * max_ray_batch          # first ray of the chunk the reference loop ends with
-            ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin)
+            if upsample_steps > 0:      # importance resampling (evaluation mode, no gradients: the caller checked)
+                ws, dep, img, ag, sigmas, rgbs = fm.render_upsample(o, d, nears, fars, int(num_steps), int(upsample_steps), last_begin)
+            else:
+                ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin)
             img = img + (1 - ws).unsqueeze(-1) * (1 if bg_color is None else bg_color)
             depth.append(dep), image.append(img), agg.append(ag)
         return {"depth": torch.stack(depth, 0), "image": torch.stack(image, 0), "rgbs": rgbs, "sigmas": sigmas,
@@ -364,13 +367,16 @@ class NeRFRenderer(nn.Module):
         the reference's loop overwrites them, and uncertain.py:80-88 consumes exactly those)."""
         if self.cuda_ray or not staged:
             return (self.run_cuda if self.cuda_ray else self.run)(rays_o, rays_d, **kwargs)
-        if self.fused and self.bg_radius <= 0 and kwargs.get("upsample_steps", 128) == 0 and not kwargs.get("perturb", False):
+        T, U = int(kwargs.get("num_steps", 128)), int(kwargs.get("upsample_steps", 128))
+        if self.fused and self.bg_radius <= 0 and not kwargs.get("perturb", False) and (U == 0 or not self.training):
             # one fused launch for the frame.  Under autograd only when nothing but the rays can ask for a gradient (frozen map: the
-            # state estimator's pose fit) -- parameters that require a gradient get it through the operators below
-            if not torch.is_grad_enabled() or self._map_is_frozen():
+            # state estimator's pose fit) -- parameters that require a gradient get it through the operators below.  With importance
+            # resampling (U > 0) only outside autograd and in evaluation mode (the fixed u of sample_pdf's `det`)
+            if not torch.is_grad_enabled() or (U == 0 and self._map_is_frozen()):
                 wants_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)
                 fm = self.fused_model()
-                if fm is not None and self._aabb_is_cube() and (not wants_grad or fm.uniform_backward_fits(int(kwargs.get("num_steps", 128)))):
+                fits = fm is not None and (fm.upsample_fits(T, U) if U > 0 else (not wants_grad or fm.uniform_backward_fits(T)))
+                if fits and self._aabb_is_cube():
                     return self._render_staged_fused(fm, rays_o, rays_d, max_ray_batch, **kwargs)
         n_cams, n_rays = rays_o.shape[:2]
         per_camera = []

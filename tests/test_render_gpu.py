@@ -297,6 +297,56 @@ def test_linear_backbone_fused_vs_operator_loop(device):
     assert abs(sa["iterations"] - sb["iterations"]) <= 2
 
 
+@pytest.mark.parametrize("backbone,T,U", [("ff", 64, 48), ("linear", 128, 128), ("ff", 33, 7)])
+def test_run_path_importance_resampling_fused_vs_operators(setup, device, backbone, T, U):
+    """NeRFRenderer.run with upsample_steps > 0 in evaluation mode: ONE fused launch (ngp_render_upsample: coarse pass, weights, CDF,
+    inverse-CDF draw, fine pass, merge, compositing, all in LDS) against the operator chain of nerf/sampling.py on the same fp16
+    network -- the chain that test_render_run_golden_fp32 pins to the reference's renderer.  F8 last-chunk tensors included; a
+    model in training mode (random u) or under autograd keeps the operators."""
+    sc = _scene(H=24, W=24)
+    model = sc.build_model(device, backbone=backbone, cuda_ray=False)
+    ro, rd = Hh.pinhole_rays(sc.poses[160], sc.intrinsics, sc.H, sc.W)
+    N = ro.shape[0]
+    kw = dict(staged=True, max_ray_batch=200, bg_color=1, perturb=False, num_steps=T, upsample_steps=U)
+    from nerfsafetyvalidation_amd import _lib
+    lib = _lib.lib()
+    res = {}
+    for fused in (True, False):
+        model.fused = fused
+        lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            res[fused] = model.render(_t(ro, device)[None], _t(rd, device)[None], **kw)
+        torch.cuda.synchronize(); lib.ngp_prof_enable(0)
+        import ctypes as C
+        ms, n, u = C.c_double(), C.c_uint64(), C.c_double()
+        launched = lib.ngp_prof_read(b"render_upsample", C.byref(ms), C.byref(n), C.byref(u)) == 0 and n.value > 0
+        assert launched == fused
+    model.fused = True
+    out, ref = res[True], res[False]
+    last = N - (N // 200) * 200 if N % 200 else 200
+    assert out["rgbs"].shape == (last, T + U, 3) == ref["rgbs"].shape and out["sigmas"].shape == ref["sigmas"].shape
+    for k, tol in (("image", 6e-4), ("depth", 5e-6)):      # 2 x the largest observed (2.7e-4, 9.5e-7)
+        a, b = out[k].float().cpu().numpy(), ref[k].float().cpu().numpy()
+        assert a.shape == b.shape
+        err = np.abs(a - b)
+        print(f"fused resampling vs operators ({backbone}, T={T}, U={U}) {k}: max {err.max():.2e} mean {err.mean():.2e}")
+        assert err.max() < tol and err.mean() < 1e-5, (k, err.max(), err.mean())
+    np.testing.assert_allclose(out["aggregated_density"].float().cpu().numpy(), ref["aggregated_density"].float().cpu().numpy(), rtol=2e-2, atol=2e-3)
+    # per-sample tensors: the resampled depths pass through sums in different orders on the two sides, a few samples move
+    sa, sb = out["sigmas"].float().cpu().numpy(), ref["sigmas"].float().cpu().numpy()
+    assert np.isclose(sa, sb, rtol=3e-2, atol=2e-3).mean() > 0.99
+    assert np.isclose(out["rgbs"].float().cpu().numpy(), ref["rgbs"].float().cpu().numpy(), rtol=0, atol=4e-3).mean() > 0.99
+    # training mode draws random u (sample_pdf det=False): operators
+    model.train()
+    lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        model.render(_t(ro, device)[None], _t(rd, device)[None], **kw)
+    torch.cuda.synchronize(); lib.ngp_prof_enable(0)
+    ms, n, u = C.c_double(), C.c_uint64(), C.c_double()
+    assert not (lib.ngp_prof_read(b"render_upsample", C.byref(ms), C.byref(n), C.byref(u)) == 0 and n.value > 0)
+    model.eval()
+
+
 def test_run_path_uniform_sampling(setup, device):
     """NeRFRenderer.run (what validate.py -O executes, cuda_ray = False): staged render, F8 last-chunk semantics."""
     sc = _scene(H=24, W=24)
