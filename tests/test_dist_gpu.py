@@ -50,6 +50,15 @@ def test_random_call_sequences_on_shared_contexts(device):
     assert "bad calls: 0" in out.stdout
 
 
+def test_training_steps_on_two_threads_while_a_third_renders(device):
+    """scripts/fuzz_training.py: optimiser steps of two models on two host threads / streams (march_rays_train, FFMLP and hash-grid
+    backward through caller-owned scratch, ngp_adam_step) with a third thread rendering frames: losses and final parameters equal
+    the same steps run alone (to the order of the fp16 table atomics), the frames bit for bit."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_training.py"), "3", "6"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "bad 0" in out.stdout
+
+
 def test_full_200_view_sweep_through_a_one_rank_rccl_group(device):
     """BASELINE configs[2] at full size -- all 200 views of the validation sweep at 800x800 -- on this box's one GPU, once without a
     process group and once through a ONE-RANK `nccl` (= RCCL) group with the tile all_gathers really issued: RCCL is loaded and
