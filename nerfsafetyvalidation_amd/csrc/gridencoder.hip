@@ -383,17 +383,19 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restric
     const uint32_t resolution = lv.resolution[level];
     float pos[D];
     uint32_t pg[D];
-    const bool valid = locate<T, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
+    bool valid = locate<T, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
     using V = Vec<T, C>;
     float g[C];
+    bool nonzero = false;
     if (valid) {
         const V gv = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
 #pragma unroll
-        for (int c = 0; c < C; c++) g[c] = (float)gv.v[c];
+        for (int c = 0; c < C; c++) { g[c] = (float)gv.v[c]; nonzero |= g[c] != 0.0f; }
     } else {
 #pragma unroll
         for (int c = 0; c < C; c++) g[c] = 0.0f;
     }
+    valid = valid && nonzero;          // a zero gradient adds nothing: no atomics (see k_grid_bwd_bin)
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float w = 1;
@@ -483,16 +485,18 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
         const uint32_t b = pb * kSmallThreads + threadIdx.x;
         float pos[D];
         uint32_t pg[D];
-        const bool valid = locate<T, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
+        bool valid = locate<T, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
         using V = Vec<T, C>;
         float g[C];
+        bool nonzero = false;
 #pragma unroll
         for (int c = 0; c < C; c++) g[c] = 0.0f;
         if (valid) {
             const V gv = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
 #pragma unroll
-            for (int c = 0; c < C; c++) g[c] = (float)gv.v[c];
+            for (int c = 0; c < C; c++) { g[c] = (float)gv.v[c]; nonzero |= g[c] != 0.0f; }
         }
+        valid = valid && nonzero;      // a zero gradient adds nothing (see k_grid_bwd_bin)
         float v[(1 << D) * C];
 #pragma unroll
         for (int idx = 0; idx < (1 << D); idx++) {
@@ -604,12 +608,16 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     const uint32_t b = blockIdx.x * NT + threadIdx.x;
     float pos[D];
     uint32_t pg[D];
-    const bool valid = locate<_Float16, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
+    bool valid = locate<_Float16, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
     float g[C] = {0.0f, 0.0f};
     if (valid) {
         const Vec<_Float16, C> gv = *reinterpret_cast<const Vec<_Float16, C>*>(grad + ((size_t)level * B + b) * C);
         g[0] = (float)gv.v[0]; g[1] = (float)gv.v[1];
     }
+    // A point whose gradient is zero adds nothing to any entry: it emits no records.  (Not a corner case: the padding rows of a
+    // training batch all sit at the origin -- ONE cell, whose eight entries' bins would overflow -- and fp16 gradients of samples
+    // behind a surface underflow to zero.)
+    valid = valid && (g[0] != 0.0f || g[1] != 0.0f);
     float v[NC * C];
 #pragma unroll
     for (int idx = 0; idx < NC; idx++) {
@@ -697,7 +705,7 @@ __global__ void __launch_bounds__(kReduceThreads) k_grid_bwd_bin_reduce(_Float16
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
     const bool hashed = lv.hashed[level] != 0;
     const uint32_t n_bins = kBinMax;
-    const uint32_t bin = blockIdx.x / kBinSplit, split = blockIdx.x % kBinSplit;
+    const uint32_t bin = blockIdx.x % kBinMax, split = blockIdx.x / kBinMax;     // (gridDim.x = kBinMax x the splits the batch can fill)
     if (bin >= n_bins) return;
     const uint32_t cap = region_cap(plan.level_records, n_bins);
     const uint32_t* fill = plan.fill + ((size_t)blockIdx.y * kBinMax + bin) * kBinShards * kFillStride;
@@ -705,7 +713,6 @@ __global__ void __launch_bounds__(kReduceThreads) k_grid_bwd_bin_reduce(_Float16
         const uint32_t n = fill[threadIdx.x * kFillStride];
         fills[threadIdx.x] = n < cap ? n : cap;
     }
-    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += kReduceThreads) acc64[i] = 0ull;
     __syncthreads();
     uint32_t total = 0;
 #pragma unroll
@@ -714,6 +721,8 @@ __global__ void __launch_bounds__(kReduceThreads) k_grid_bwd_bin_reduce(_Float16
     uint32_t n_split = 1;
     while (n_split < kBinSplit && total >= 2 * n_split * kBinSplitMin) n_split *= 2;
     if (split >= n_split || total == 0) return;
+    for (uint32_t i = threadIdx.x; i < kBinEntries * 2; i += kReduceThreads) acc64[i] = 0ull;
+    __syncthreads();
     const uint2* base = plan.records + (size_t)blockIdx.y * plan.level_records + (size_t)bin * kBinShards * cap;
     auto add = [&](uint32_t key, uint32_t val) {
         const uint32_t slot = key & (kBinEntries - 1);
@@ -891,7 +900,10 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
                 (void)hipMemsetAsync(plan.fill, 0, (size_t)n * kBinMax * kBinShards * kFillStride * sizeof(uint32_t), s);
                 k_grid_bwd_bin<D, NT><<<dim3(n_pb, n), NT, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype, ac, bl,
                                                                           first, plan);
-                k_grid_bwd_bin_reduce<<<dim3(kBinMax * kBinSplit, n), kReduceThreads, lds_red, s>>>((_Float16*)grad_emb, lv, bl, first, plan);
+                // a bin holds at most 32 regions of `cap` records: no more reducing workgroups than that can keep busy
+                uint32_t max_split = 1;
+                while (max_split < kBinSplit && (size_t)level_records / kBinMax >= (size_t)2 * max_split * kBinSplitMin) max_split *= 2;
+                k_grid_bwd_bin_reduce<<<dim3(kBinMax * max_split, n), kReduceThreads, lds_red, s>>>((_Float16*)grad_emb, lv, bl, first, plan);
                 if (getenv("NGP_GRID_BWD_STATS")) {      // diagnostics: how evenly the regions filled
                     std::vector<uint32_t> h((size_t)n * kBinMax * kBinShards * kFillStride);
                     (void)hipStreamSynchronize(s);

@@ -23,15 +23,19 @@ _gridtype_to_id = {"hash": 0, "tiled": 1}
 # ---------------------------------------------------------------------------------------------------------------------------
 # Derived copies of a table, kept per PARAMETER and per version of it: the fp16 copy autocast asks for on every forward
 # (grid.py:38-39 converts all 12.6 M entries per call) and, once the table has been seen unchanged a second time outside autograd
-# (or an eighth time at all) -- i.e. it is being evaluated, not trained -- its per-cell corner records (ngp_build_cell_tables: 32 bytes per grid cell of the
+# (or an eighth time at all) and has encoded 64 M points -- i.e. it is being evaluated, not trained -- its per-cell corner records (ngp_build_cell_tables: 32 bytes per grid cell of the
 # first twelve levels, 38 GB for the bound-2 table, within a budget).  The operator and the fused kernels (_fused.FusedModel)
 # share one entry.  Both are value copies: results do not depend on them.
 # ---------------------------------------------------------------------------------------------------------------------------
+_CELLS_AFTER_POINTS = 64 * 1024 * 1024
+
+
 class DerivedTables:
     def __init__(self, param):
         self.key = (param.data_ptr(), param._version, param.device)
         self.emb16 = param.detach().to(torch.half).contiguous()
         self.seen = 1
+        self.points = 0                       # points encoded with this version of the table (operator calls)
         self.cells, self.cell_levels, self.cells_tried = None, 0, False
         self.lock = threading.Lock()
 
@@ -111,7 +115,11 @@ class _grid_encode(Function):
             if embeddings.dtype == torch.float32 and isinstance(embeddings, nn.Parameter):
                 ent = derived_tables(embeddings)
                 embeddings = ent.emb16
-                if ((ent.seen >= 2 and not torch.is_grad_enabled()) or ent.seen >= 8) and D == 3 and C == 2 and L == 16:
+                # the records take ~9 ms to build and save ~30 % of a forward: worth it once this version of the table has encoded
+                # tens of millions of points (a frame rendered operator by operator), not for the few chunks of a density-grid
+                # update between two optimiser steps
+                ent.points += B
+                if ent.points >= _CELLS_AFTER_POINTS and ((ent.seen >= 2 and not torch.is_grad_enabled()) or ent.seen >= 8) and D == 3 and C == 2 and L == 16:
                     cells, cell_levels = ent.ensure_cells(_lib.host_i32(offsets), S, H, gridtype, align_corners)
             else:
                 embeddings = embeddings.to(torch.half)

@@ -52,6 +52,8 @@ model.train()
 model.mean_count = 48 * N           # sample capacity of march_rays_train (the reference's running mean, renderer.py:296)
 opt = Adam(model.parameters(), lr=1e-3)
 REPS = 3
+LOSS_SCALE = 65536.0
+grad_nonzero = None
 M = None
 for it in range(1 + REPS):
     if it == 1:
@@ -61,7 +63,15 @@ for it in range(1 + REPS):
         out = model.render(rays["rays_o"], rays["rays_d"], staged=False, bg_color=1, perturb=True, force_all_rays=False)
     loss = out["image"].float().square().mean()
     opt.zero_grad(set_to_none=True)
-    loss.backward()
+    # fp16 training runs under torch.cuda.amp.GradScaler (nerf/utils.py:350, init_scale 2^16): without the scale the gradients of a
+    # 640 k-ray mean underflow to zero in fp16 and the backward kernels -- which skip zero gradients -- would have nothing to do
+    (loss * LOSS_SCALE).backward()
+    if it == REPS:
+        g = model.encoder.embeddings.grad
+        grad_nonzero = float((g != 0).any(dim=-1).float().mean())
+    for p_ in model.parameters():
+        if p_.grad is not None:
+            p_.grad.div_(LOSS_SCALE)
     opt.step()
     M = int(model.step_counter[(model.local_step - 1) % 16][0].item())
 torch.cuda.synchronize(); lib.ngp_prof_enable(0)
@@ -84,7 +94,9 @@ line("ffmlp_backward (both nets, averaged: activation + weight gradients in one 
           "moved 1472 B per row (activation gradients written and read back, activations read twice) and its table priced those")
 # (sh_encode_backward is not launched by a training step -- view directions carry no gradient there -- it is timed below, on
 #  the pose-gradient shape where it does run)
-line("grid_encode_backward f16 (table gradient, packed-half atomics)", "grid_encode_backward", Mp, "points", 588 * Mp)
+line("grid_encode_backward f16 (table gradient, packed-half atomics)", "grid_encode_backward", Mp, "points", 588 * Mp,
+     note=f"gradients of the scaled loss (x {int(LOSS_SCALE)}, as under GradScaler); table entries with a non-zero gradient: {grad_nonzero:.3f}; points whose fp16 "
+          "gradient is zero are skipped by the kernels")
 line("adam_step (all parameters, averaged over the 3 tensors)", "adam_step", n_param / 3, "params", 28 * n_param / 3)
 
 # ---------------------------------------------------------------- eval-loop operators on the first iterations' shapes

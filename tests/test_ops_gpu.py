@@ -572,11 +572,14 @@ def test_grid_encode_forward_through_cell_records_bit_exact(device, gridtype, al
                                                _lib.NGP_F16, _lib.ptr(cells), 20, _lib.stream()), "grid_encode_forward")
 
 
-def test_grid_encoder_module_keeps_derived_tables_per_parameter_version(device):
+def test_grid_encoder_module_keeps_derived_tables_per_parameter_version(device, monkeypatch):
     """GridEncoder under autocast: the fp16 copy of the table is made once per parameter version, the per-cell records appear when
-    the same version is evaluated again outside autograd, an in-place update drops both, and the outputs never change."""
+    the same version is evaluated again outside autograd and has encoded enough points to pay for them, an in-place update drops
+    both, and the outputs never change."""
     from nerfsafetyvalidation_amd.gridencoder import GridEncoder
+    from nerfsafetyvalidation_amd.gridencoder import grid as G
     from nerfsafetyvalidation_amd.gridencoder.grid import derived_tables
+    monkeypatch.setattr(G, "_CELLS_AFTER_POINTS", 6000)       # (64 M points in production: the records take ~9 ms to build)
     enc = GridEncoder(desired_resolution=256).to(device)
     with torch.no_grad():
         enc.embeddings.uniform_(-0.5, 0.5)
