@@ -586,12 +586,23 @@ struct BinPlan {     // workspace layout of one launch group (device pointers)
     size_t level_records;   // records per level (all regions)
 };
 
-template <int D, int NT>
+// MERGE (the coarser levels, where the rays of one workgroup -- neighbouring pixels -- cross the same cells): before the sort, the
+// row totals go through a small LDS hash table keyed by (bin, slot) with 64-bit fixed-point sums (units of 2^-26; integer LDS
+// atomics, see k_grid_bwd_bin_reduce), so that an entry touched by many rays of the workgroup leaves it as ONE record.  A key that
+// finds no slot within four probes is emitted directly, like every record of the plain variant.  Staging holds half as many
+// records then; what does not fit goes straight to the table.
+constexpr uint32_t kMergeSlots = 1024, kMergeEmpty = 0xFFFFFFFFu;
+constexpr float kMergeScale = 0x1p26f, kMergeInvScale = 0x1p-26f;
+template <int D, int NT, bool MERGE>
 __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs,
                                                      _Float16* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
                                                      bool align_corners, BinLevels bl, uint32_t first, BinPlan plan) {
     constexpr int C = 2, NC = 1 << D;
-    extern __shared__ uint2 rec[];                       // [NT * NC] records sorted by bin
+    constexpr uint32_t RC = MERGE ? NT * NC / 2 : NT * NC;          // staged records
+    static_assert(!MERGE || NT >= (int)kMergeSlots, "one thread per table slot");
+    extern __shared__ uint2 rec[];                       // [RC] records sorted by bin (+ MERGE: table keys [kMergeSlots], sums [kMergeSlots][2])
+    uint32_t* tkey = reinterpret_cast<uint32_t*>(rec + RC);
+    unsigned long long* tval = reinterpret_cast<unsigned long long*>(tkey + kMergeSlots);
     __shared__ uint32_t cnt[kBinMax], off[kBinMax], gbase[kBinMax];
     const uint32_t level = bl.level[first + blockIdx.y];
     _Float16* tab = grad_grid + (size_t)lv.offset[level] * C;
@@ -604,6 +615,9 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     uint2* region = plan.records + (size_t)blockIdx.y * plan.level_records;
     uint32_t* fill = plan.fill + ((size_t)blockIdx.y * kBinMax * kBinShards + shard) * kFillStride;
     if (threadIdx.x < kBinMax) cnt[threadIdx.x] = 0;
+    if (MERGE) {
+        for (uint32_t i = threadIdx.x; i < kMergeSlots; i += NT) { tkey[i] = kMergeEmpty; tval[2 * i] = 0ull; tval[2 * i + 1] = 0ull; }
+    }
     __syncthreads();
     const uint32_t b = blockIdx.x * NT + threadIdx.x;
     float pos[D];
@@ -628,7 +642,14 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     }
     const uint32_t lane = threadIdx.x & 63u;
     const bool tail = merge_cell_rows<D>(valid, pg, v);
-    uint32_t key[NC], val[NC];                            // slot | bin << 12 | rank in the bin << 19;  the two halves
+    // finite halves only (the reference's half atomics would carry an overflowed sum as inf; the fixed-point slice cannot)
+    auto to_half2 = [](float a, float c) {
+        const __half2 h = __halves2half2(__float2half_rn(fminf(fmaxf(a, -65504.0f), 65504.0f)), __float2half_rn(fminf(fmaxf(c, -65504.0f), 65504.0f)));
+        return *reinterpret_cast<const uint32_t*>(&h);
+    };
+    uint32_t key[NC], val[NC];                            // slot | bin << 12 | rank in the bin << 19 (kMergeEmpty: nothing);  the two halves
+#pragma unroll
+    for (int idx = 0; idx < NC; idx++) key[idx] = kMergeEmpty;
     if (tail) {
 #pragma unroll
         for (int idx = 0; idx < NC; idx++) {
@@ -637,41 +658,77 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
             for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
             const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
             const uint32_t bin = bin_of(e, hashed);
-            const uint32_t r = atomicAdd(&cnt[bin], 1u);
-            // finite halves only (the reference's half atomics would carry an overflowed sum as inf; the fixed-point slice cannot)
-            const __half2 h = __halves2half2(__float2half_rn(fminf(fmaxf(v[idx * 2], -65504.0f), 65504.0f)),
-                                             __float2half_rn(fminf(fmaxf(v[idx * 2 + 1], -65504.0f), 65504.0f)));
-            key[idx] = slot_of(e, hashed) | (bin << kBinLog) | (r << 19);
-            val[idx] = *reinterpret_cast<const uint32_t*>(&h);
+            const uint32_t k19 = slot_of(e, hashed) | (bin << kBinLog);
+            bool in_table = false;
+            if (MERGE) {
+                const uint32_t h = (k19 * 2654435761u) >> 22;
+#pragma unroll
+                for (uint32_t pr = 0; pr < 4 && !in_table; pr++) {
+                    const uint32_t sl = (h + pr) & (kMergeSlots - 1);
+                    const uint32_t old = atomicCAS(&tkey[sl], kMergeEmpty, k19);
+                    if (old == kMergeEmpty || old == k19) {
+                        atomicAdd(&tval[2 * sl], (unsigned long long)__float2ll_rn(v[idx * 2] * kMergeScale));
+                        atomicAdd(&tval[2 * sl + 1], (unsigned long long)__float2ll_rn(v[idx * 2 + 1] * kMergeScale));
+                        in_table = true;
+                    }
+                }
+            }
+            if (!in_table) {
+                const uint32_t r = atomicAdd(&cnt[bin], 1u);
+                key[idx] = k19 | (r << 19);
+                val[idx] = to_half2(v[idx * 2], v[idx * 2 + 1]);
+            }
+        }
+    }
+    uint32_t tk = kMergeEmpty, tr = 0, tv = 0;            // MERGE: the table slot this thread turns into a record
+    if (MERGE) {
+        __syncthreads();
+        if (threadIdx.x < kMergeSlots && tkey[threadIdx.x] != kMergeEmpty) {
+            tv = to_half2((float)(long long)tval[2 * threadIdx.x] * kMergeInvScale, (float)(long long)tval[2 * threadIdx.x + 1] * kMergeInvScale);
+            if (tv & 0x7FFF7FFFu) {                       // (sums that cancelled or rounded to zero add nothing)
+                tk = tkey[threadIdx.x];
+                tr = atomicAdd(&cnt[tk >> kBinLog], 1u);
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {            // wave 0: exclusive scan of the 128 counts, room in the regions
+    if (threadIdx.x < 64) {            // wave 0: exclusive scan of the 128 counts, room in the regions for what the staging holds
         const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
-        uint32_t g0 = 0, g1 = 0;
-        if (c0) g0 = atomicAdd(&fill[(2 * lane) * kBinShards * kFillStride], c0);
-        if (c1) g1 = atomicAdd(&fill[(2 * lane + 1) * kBinShards * kFillStride], c1);
         uint32_t incl = c0 + c1;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(incl, o, 64);
             if (lane >= (uint32_t)o) incl += up;
         }
-        off[2 * lane] = incl - c0 - c1;
-        off[2 * lane + 1] = incl - c1;
+        const uint32_t o0 = incl - c0 - c1, o1 = incl - c1;
+        const uint32_t s0 = o0 >= RC ? 0u : (c0 < RC - o0 ? c0 : RC - o0), s1 = o1 >= RC ? 0u : (c1 < RC - o1 ? c1 : RC - o1);
+        uint32_t g0 = 0, g1 = 0;
+        if (s0) g0 = atomicAdd(&fill[(2 * lane) * kBinShards * kFillStride], s0);
+        if (s1) g1 = atomicAdd(&fill[(2 * lane + 1) * kBinShards * kFillStride], s1);
+        off[2 * lane] = o0;
+        off[2 * lane + 1] = o1;
         gbase[2 * lane] = g0;
         gbase[2 * lane + 1] = g1;
     }
     __syncthreads();
-    if (tail) {
-#pragma unroll
-        for (int idx = 0; idx < NC; idx++) {
-            const uint32_t bin = (key[idx] >> kBinLog) & (kBinMax - 1);
-            rec[off[bin] + (key[idx] >> 19)] = make_uint2(key[idx] & ((1u << 19) - 1), val[idx]);
+    auto place = [&](uint32_t k19, uint32_t rank, uint32_t halves) {
+        const uint32_t bin = k19 >> kBinLog;
+        const uint32_t at = off[bin] + rank;
+        if (at < RC) {
+            rec[at] = make_uint2(k19, halves);
+        } else {                                          // staging full (MERGE only): straight to the table
+            const __half2 h = *reinterpret_cast<const __half2*>(&halves);
+            const float vv[2] = {__low2float(h), __high2float(h)};
+            table_add<_Float16, C>(tab, entry_of(bin, k19 & (kBinEntries - 1), hashed), vv);
         }
-    }
+    };
+#pragma unroll
+    for (int idx = 0; idx < NC; idx++)
+        if (key[idx] != kMergeEmpty) place(key[idx] & ((1u << 19) - 1), key[idx] >> 19, val[idx]);
+    if (MERGE && tk != kMergeEmpty) place(tk, tr, tv);
     __syncthreads();
-    const uint32_t total = off[kBinMax - 1] + cnt[kBinMax - 1];
+    uint32_t total = off[kBinMax - 1] + cnt[kBinMax - 1];
+    total = total < RC ? total : RC;
     for (uint32_t i = threadIdx.x; i < total; i += NT) {
         const uint2 r = rec[i];
         const uint32_t bin = r.x >> kBinLog;
@@ -763,6 +820,15 @@ __global__ void __launch_bounds__(kReduceThreads) k_grid_bwd_bin_reduce(_Float16
 constexpr size_t kBinWorkspaceMax = (size_t)4 << 30;    // levels are processed in groups that fit this
 static bool g4_off() {                                   // diagnostics (NGP_GRID_NO_G4 set): the one-lane-per-(point, level) kernel for every shape
     static const bool off = getenv("NGP_GRID_NO_G4") != nullptr;
+    return off;
+}
+constexpr uint32_t kMergeMaxRes = 1024;                   // levels up to this resolution merge across the rays of a workgroup (k_grid_bwd_bin<MERGE>)
+static uint32_t merge_max_res() {                        // (NGP_GRID_MERGE_RES overrides the threshold: diagnostics)
+    static const uint32_t v = getenv("NGP_GRID_MERGE_RES") ? (uint32_t)atoi(getenv("NGP_GRID_MERGE_RES")) : kMergeMaxRes;
+    return v;
+}
+static bool merge_off() {                                // diagnostics (NGP_GRID_NO_MERGE set): the plain first pass for every level
+    static const bool off = getenv("NGP_GRID_NO_MERGE") != nullptr;
     return off;
 }
 static bool bin_off() {                                  // diagnostics (NGP_GRID_NO_BINS set): atomics for every level
@@ -875,9 +941,16 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
     if constexpr (sizeof(T) == 2 && C == 2) {
         BinLevels bl = {};
         uint32_t n_bin = 0;
+        // the levels whose cells the neighbouring rays of a workgroup share come first: they take the merging variant of the first pass
+        uint32_t n_merge = 0;
         if (!bin_off() && B >= 128u * 1024u)
-            for (uint32_t l = 0; l < L; l++)
-                if (!((small_mask >> l) & 1u) && lv.offset[l + 1] - lv.offset[l] <= kBinMax * kBinEntries) bl.level[n_bin++] = l;
+            for (int pass = 0; pass < 2; pass++) {
+                for (uint32_t l = 0; l < L; l++) {
+                    const bool merge = lv.resolution[l] <= merge_max_res() && !merge_off();
+                    if (merge == (pass == 0) && !((small_mask >> l) & 1u) && lv.offset[l + 1] - lv.offset[l] <= kBinMax * kBinEntries) bl.level[n_bin++] = l;
+                }
+                if (pass == 0) n_merge = n_bin;
+            }
         const size_t level_records = bin_level_records(B, 1u << D);
         const size_t per_level = bin_level_bytes(B, 1u << D);
         const size_t usable = workspace ? (workspace_bytes < kBinWorkspaceMax ? workspace_bytes : kBinWorkspaceMax) : 0;
@@ -888,18 +961,26 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
             constexpr uint32_t NT = 1024;
             const uint32_t n_pb = div_up(B, NT);
             const size_t lds_bin = (size_t)NT * (1u << D) * sizeof(uint2);
-            ensure_dynamic_lds((const void*)k_grid_bwd_bin<D, NT>, (int)lds_bin);
+            const size_t lds_merge = lds_bin / 2 + (size_t)kMergeSlots * (sizeof(uint32_t) + 2 * sizeof(unsigned long long));
+            ensure_dynamic_lds((const void*)k_grid_bwd_bin<D, NT, false>, (int)lds_bin);
+            ensure_dynamic_lds((const void*)k_grid_bwd_bin<D, NT, true>, (int)lds_merge);
             const size_t lds_red = (size_t)kBinEntries * 2 * sizeof(unsigned long long);
             ensure_dynamic_lds((const void*)k_grid_bwd_bin_reduce, (int)lds_red);
             BinPlan plan;
             plan.records = reinterpret_cast<uint2*>(ws);
             plan.fill = reinterpret_cast<uint32_t*>(ws + (size_t)group * level_records * sizeof(uint2));
             plan.level_records = level_records;
-            for (uint32_t first = 0; first < n_bin; first += group) {
-                const uint32_t n = n_bin - first < group ? n_bin - first : group;
+            for (uint32_t first = 0, n = 0; first < n_bin; first += n) {
+                const bool merge = first < n_merge;
+                const uint32_t left = (merge ? n_merge : n_bin) - first;           // (a group does not mix the two variants)
+                n = left < group ? left : group;
                 (void)hipMemsetAsync(plan.fill, 0, (size_t)n * kBinMax * kBinShards * kFillStride * sizeof(uint32_t), s);
-                k_grid_bwd_bin<D, NT><<<dim3(n_pb, n), NT, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype, ac, bl,
-                                                                          first, plan);
+                if (merge)
+                    k_grid_bwd_bin<D, NT, true><<<dim3(n_pb, n), NT, lds_merge, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype,
+                                                                                     ac, bl, first, plan);
+                else
+                    k_grid_bwd_bin<D, NT, false><<<dim3(n_pb, n), NT, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype,
+                                                                                    ac, bl, first, plan);
                 // a bin holds at most 32 regions of `cap` records: no more reducing workgroups than that can keep busy
                 uint32_t max_split = 1;
                 while (max_split < kBinSplit && (size_t)level_records / kBinMax >= (size_t)2 * max_split * kBinSplitMin) max_split *= 2;
