@@ -590,7 +590,7 @@ struct BinPlan {     // workspace layout of one launch group (device pointers)
 // row totals go through a small LDS hash table keyed by (bin, slot) with 64-bit fixed-point sums (units of 2^-26; integer LDS
 // atomics, see k_grid_bwd_bin_reduce), so that an entry touched by many rays of the workgroup leaves it as ONE record.  A key that
 // finds no slot within four probes is emitted directly, like every record of the plain variant.  Staging holds half as many
-// records then; what does not fit goes straight to the table.
+// records then; a workgroup that found little to merge (points in no particular order) empties it in two or three windows.
 constexpr uint32_t kMergeSlots = 1024, kMergeEmpty = 0xFFFFFFFFu;
 constexpr float kMergeScale = 0x1p26f, kMergeInvScale = 0x1p-26f;
 template <int D, int NT, bool MERGE>
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     extern __shared__ uint2 rec[];                       // [RC] records sorted by bin (+ MERGE: table keys [kMergeSlots], sums [kMergeSlots][2])
     uint32_t* tkey = reinterpret_cast<uint32_t*>(rec + RC);
     unsigned long long* tval = reinterpret_cast<unsigned long long*>(tkey + kMergeSlots);
-    __shared__ uint32_t cnt[kBinMax], off[kBinMax], gbase[kBinMax];
+    __shared__ uint32_t cnt[kBinMax], off[kBinMax], gbase[kBinMax], wlo[kBinMax];
     const uint32_t level = bl.level[first + blockIdx.y];
     _Float16* tab = grad_grid + (size_t)lv.offset[level] * C;
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {            // wave 0: exclusive scan of the 128 counts, room in the regions for what the staging holds
+    if (threadIdx.x < 64) {            // wave 0: exclusive scan of the 128 counts
         const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
         uint32_t incl = c0 + c1;
 #pragma unroll
@@ -700,46 +700,45 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
             const uint32_t up = __shfl_up(incl, o, 64);
             if (lane >= (uint32_t)o) incl += up;
         }
-        const uint32_t o0 = incl - c0 - c1, o1 = incl - c1;
-        const uint32_t s0 = o0 >= RC ? 0u : (c0 < RC - o0 ? c0 : RC - o0), s1 = o1 >= RC ? 0u : (c1 < RC - o1 ? c1 : RC - o1);
-        uint32_t g0 = 0, g1 = 0;
-        if (s0) g0 = atomicAdd(&fill[(2 * lane) * kBinShards * kFillStride], s0);
-        if (s1) g1 = atomicAdd(&fill[(2 * lane + 1) * kBinShards * kFillStride], s1);
-        off[2 * lane] = o0;
-        off[2 * lane + 1] = o1;
-        gbase[2 * lane] = g0;
-        gbase[2 * lane + 1] = g1;
+        off[2 * lane] = incl - c0 - c1;
+        off[2 * lane + 1] = incl - c1;
     }
     __syncthreads();
-    auto place = [&](uint32_t k19, uint32_t rank, uint32_t halves) {
-        const uint32_t bin = k19 >> kBinLog;
-        const uint32_t at = off[bin] + rank;
-        if (at < RC) {
-            rec[at] = make_uint2(k19, halves);
-        } else {                                          // staging full (MERGE only): straight to the table
-            const __half2 h = *reinterpret_cast<const __half2*>(&halves);
-            const float vv[2] = {__low2float(h), __high2float(h)};
-            table_add<_Float16, C>(tab, entry_of(bin, k19 & (kBinEntries - 1), hashed), vv);
+    // The sorted sequence leaves through the staging buffer in windows of RC records (one window, except when a MERGE workgroup
+    // found little to merge): per window and bin one reservation in the bin's region, then contiguous copies.
+    const uint32_t total = off[kBinMax - 1] + cnt[kBinMax - 1];
+    for (uint32_t base = 0; base < total; base += RC) {
+        if (threadIdx.x < kBinMax) {
+            const uint32_t o = off[threadIdx.x], c = cnt[threadIdx.x];
+            const uint32_t lo = o > base ? o : base, hi = o + c < base + RC ? o + c : base + RC;
+            uint32_t g0 = 0;
+            if (hi > lo) g0 = atomicAdd(&fill[threadIdx.x * kBinShards * kFillStride], hi - lo);
+            gbase[threadIdx.x] = g0;
+            wlo[threadIdx.x] = lo;
         }
-    };
+        auto place = [&](uint32_t k19, uint32_t rank, uint32_t halves) {
+            const uint32_t at = off[k19 >> kBinLog] + rank;
+            if (at >= base && at - base < RC) rec[at - base] = make_uint2(k19, halves);
+        };
 #pragma unroll
-    for (int idx = 0; idx < NC; idx++)
-        if (key[idx] != kMergeEmpty) place(key[idx] & ((1u << 19) - 1), key[idx] >> 19, val[idx]);
-    if (MERGE && tk != kMergeEmpty) place(tk, tr, tv);
-    __syncthreads();
-    uint32_t total = off[kBinMax - 1] + cnt[kBinMax - 1];
-    total = total < RC ? total : RC;
-    for (uint32_t i = threadIdx.x; i < total; i += NT) {
-        const uint2 r = rec[i];
-        const uint32_t bin = r.x >> kBinLog;
-        const uint32_t at = gbase[bin] + (i - off[bin]);
-        if (at < cap) {
-            region[((size_t)bin * kBinShards + shard) * cap + at] = r;
-        } else {                                          // region full: straight to the table
-            const __half2 h = *reinterpret_cast<const __half2*>(&r.y);
-            const float vv[2] = {__low2float(h), __high2float(h)};
-            table_add<_Float16, C>(tab, entry_of(bin, r.x & (kBinEntries - 1), hashed), vv);
+        for (int idx = 0; idx < NC; idx++)
+            if (key[idx] != kMergeEmpty) place(key[idx] & ((1u << 19) - 1), key[idx] >> 19, val[idx]);
+        if (MERGE && tk != kMergeEmpty) place(tk, tr, tv);
+        __syncthreads();
+        const uint32_t n_win = total - base < RC ? total - base : RC;
+        for (uint32_t i = threadIdx.x; i < n_win; i += NT) {
+            const uint2 r = rec[i];
+            const uint32_t bin = r.x >> kBinLog;
+            const uint32_t at = gbase[bin] + (base + i - wlo[bin]);
+            if (at < cap) {
+                region[((size_t)bin * kBinShards + shard) * cap + at] = r;
+            } else {                                          // region full: straight to the table
+                const __half2 h = *reinterpret_cast<const __half2*>(&r.y);
+                const float vv[2] = {__low2float(h), __high2float(h)};
+                table_add<_Float16, C>(tab, entry_of(bin, r.x & (kBinEntries - 1), hashed), vv);
+            }
         }
+        __syncthreads();
     }
 }
 
