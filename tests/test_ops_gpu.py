@@ -364,7 +364,10 @@ def test_ffmlp_inference_and_forward(device, hidden, in_dim, num_layers, B):
 @pytest.mark.parametrize("hidden,in_dim,num_layers,B,act", [(64, 32, 2, 1000, "relu"), (64, 64, 3, 4096, "relu"), (16, 16, 2, 77, "relu"),
                                                             (32, 48, 4, 300, "relu"), (128, 32, 2, 700, "relu"), (256, 64, 3, 260, "relu"),
                                                             (64, 32, 2, 200, "sigmoid"), (32, 32, 3, 130, "squareplus"),
-                                                            (64, 32, 2, 9000, "relu")])
+                                                            (64, 32, 2, 9000, "relu"),
+                                                            # every shape of the one-pass form (k_ffmlp_bwd_fused): input blocks 1-4, 1-3 hidden matrices
+                                                            (64, 16, 2, 200, "relu"), (64, 48, 3, 50, "relu"), (64, 64, 4, 333, "relu"),
+                                                            (64, 32, 4, 2048, "squareplus"), (64, 32, 5, 300, "relu")])
 def test_ffmlp_backward(device, hidden, in_dim, num_layers, B, act):
     """ngp_ffmlp_backward through the FFMLP module vs the oracle restatement of ffmlp.cu:410-520/:745-897."""
     from nerfsafetyvalidation_amd.ffmlp import FFMLP

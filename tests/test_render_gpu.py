@@ -306,6 +306,8 @@ def test_run_path_importance_resampling_fused_vs_operators(setup, device, backbo
     sc = _scene(H=24, W=24)
     model = sc.build_model(device, backbone=backbone, cuda_ray=False)
     ro, rd = Hh.pinhole_rays(sc.poses[160], sc.intrinsics, sc.H, sc.W)
+    rd[5:9] = -rd[5:9]                      # a few rays that leave the box behind the camera or miss it: near == far, NaN depth
+    ro[7] = ro[7] * 3
     N = ro.shape[0]
     kw = dict(staged=True, max_ray_batch=200, bg_color=1, perturb=False, num_steps=T, upsample_steps=U)
     from nerfsafetyvalidation_amd import _lib
@@ -327,7 +329,8 @@ def test_run_path_importance_resampling_fused_vs_operators(setup, device, backbo
     assert out["rgbs"].shape == (last, T + U, 3) == ref["rgbs"].shape and out["sigmas"].shape == ref["sigmas"].shape
     for k, tol in (("image", 6e-4), ("depth", 5e-6)):      # 2 x the largest observed (2.7e-4, 9.5e-7)
         a, b = out[k].float().cpu().numpy(), ref[k].float().cpu().numpy()
-        assert a.shape == b.shape
+        assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b))
+        a, b = np.nan_to_num(a), np.nan_to_num(b)
         err = np.abs(a - b)
         print(f"fused resampling vs operators ({backbone}, T={T}, U={U}) {k}: max {err.max():.2e} mean {err.mean():.2e}")
         assert err.max() < tol and err.mean() < 1e-5, (k, err.max(), err.mean())
