@@ -515,7 +515,17 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
                 const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    if constexpr (sizeof(T) == 2) atomicAdd(&acc[e * C + c], (unsigned long long)__float2ll_rn(v[idx * C + c] * kSmallScale));
+                    if constexpr (sizeof(T) == 2) {
+                        const float x = v[idx * C + c];
+                        if (fabsf(x) <= 65504.0f) {
+                            atomicAdd(&acc[e * C + c], (unsigned long long)__float2ll_rn(x * kSmallScale));
+                        } else {                           // inf / NaN / beyond fp16: straight to the table, where it is inf as in the reference
+                            float one[C];
+#pragma unroll
+                            for (int k = 0; k < C; k++) one[k] = k == c ? x : 0.0f;
+                            table_add<T, C>(tab, e, one);
+                        }
+                    }
                     else atomicAdd(reinterpret_cast<float*>(acc) + e * C + c, v[idx * C + c]);     // fp32 tables: no bound on the gradients' range
                 }
             }
@@ -642,11 +652,14 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     }
     const uint32_t lane = threadIdx.x & 63u;
     const bool tail = merge_cell_rows<D>(valid, pg, v);
-    // finite halves only (the reference's half atomics would carry an overflowed sum as inf; the fixed-point slice cannot)
     auto to_half2 = [](float a, float c) {
-        const __half2 h = __halves2half2(__float2half_rn(fminf(fmaxf(a, -65504.0f), 65504.0f)), __float2half_rn(fminf(fmaxf(c, -65504.0f), 65504.0f)));
+        const __half2 h = __halves2half2(__float2half_rn(a), __float2half_rn(c));
         return *reinterpret_cast<const uint32_t*>(&h);
     };
+    // The records and the fixed-point sums hold finite halves only.  An update that is inf / NaN in fp16 -- an overflowed gradient,
+    // which the loss scaler must be able to SEE in the table gradient (GradScaler backs off on it, nerf/utils.py:674-676) -- goes
+    // straight to the table with the reference's atomic and poisons its entry exactly as it does there.
+    auto nonfinite = [](uint32_t hv) { return (hv & 0x7C00u) == 0x7C00u || (hv & 0x7C000000u) == 0x7C000000u; };
     uint32_t key[NC], val[NC];                            // slot | bin << 12 | rank in the bin << 19 (kMergeEmpty: nothing);  the two halves
 #pragma unroll
     for (int idx = 0; idx < NC; idx++) key[idx] = kMergeEmpty;
@@ -659,6 +672,12 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
             const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
             const uint32_t bin = bin_of(e, hashed);
             const uint32_t k19 = slot_of(e, hashed) | (bin << kBinLog);
+            const uint32_t hv = to_half2(v[idx * 2], v[idx * 2 + 1]);
+            if (nonfinite(hv)) {
+                const float vv[2] = {v[idx * 2], v[idx * 2 + 1]};
+                table_add<_Float16, C>(tab, e, vv);
+                continue;
+            }
             bool in_table = false;
             if (MERGE) {
                 const uint32_t h = (k19 * 2654435761u) >> 22;
@@ -676,7 +695,7 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
             if (!in_table) {
                 const uint32_t r = atomicAdd(&cnt[bin], 1u);
                 key[idx] = k19 | (r << 19);
-                val[idx] = to_half2(v[idx * 2], v[idx * 2 + 1]);
+                val[idx] = hv;
             }
         }
     }
@@ -684,9 +703,14 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     if (MERGE) {
         __syncthreads();
         if (threadIdx.x < kMergeSlots && tkey[threadIdx.x] != kMergeEmpty) {
-            tv = to_half2((float)(long long)tval[2 * threadIdx.x] * kMergeInvScale, (float)(long long)tval[2 * threadIdx.x + 1] * kMergeInvScale);
-            if (tv & 0x7FFF7FFFu) {                       // (sums that cancelled or rounded to zero add nothing)
-                tk = tkey[threadIdx.x];
+            const float s0 = (float)(long long)tval[2 * threadIdx.x] * kMergeInvScale, s1 = (float)(long long)tval[2 * threadIdx.x + 1] * kMergeInvScale;
+            tv = to_half2(s0, s1);
+            const uint32_t k19 = tkey[threadIdx.x];
+            if (nonfinite(tv)) {                          // the merged sum left the fp16 range: the table entry becomes inf, as in the reference
+                const float vv[2] = {s0, s1};
+                table_add<_Float16, C>(tab, entry_of(k19 >> kBinLog, k19 & (kBinEntries - 1), hashed), vv);
+            } else if (tv & 0x7FFF7FFFu) {                // (sums that cancelled or rounded to zero add nothing)
+                tk = k19;
                 tr = atomicAdd(&cnt[tk >> kBinLog], 1u);
             }
         }

@@ -309,6 +309,23 @@ def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_p
     touched = np.abs(want).sum(-1) > 0
     assert np.array_equal(np.abs(got).sum(-1) > 0, touched) or dtype == np.float16
     gi_full = xt.grad.cpu().numpy().copy()
+    # An overflowed gradient (inf / NaN in fp16) must reach the table gradient: the loss scaler reads it there (GradScaler skips the
+    # step and backs off, nerf/utils.py:674-676).  The same entries as in the oracle's scatter become non-finite, no others.
+    if dtype == np.float16:
+        g2 = g.copy()
+        g2[100, 0::2] = np.inf
+        g2[min(5000, B - 1), 1::2] = np.nan
+        g2[B // 2, :] = 60000.0                                  # finite, but eight points of weight ~1 would not be: stays finite here
+        ge2 = np.zeros((offsets[-1], C), np.float32)
+        gl2 = np.ascontiguousarray(g2.reshape(B, L, C).transpose(1, 0, 2))
+        with np.errstate(invalid="ignore", over="ignore"):
+            O.grid_encode_backward(gl2.astype(np.float32), x, emb.astype(np.float32), offsets, ge2, B, D, C, L, float(np.log2(pls)), 16, False,
+                                   dydx.astype(np.float32), np.zeros((B, D), np.float32), 0, False)
+        embt2 = _t(emb, device).requires_grad_(True)
+        grid_encode(_t(x, device), embt2, _t(offsets, device), pls, 16, False, 0, False).backward(_t(g2, device))
+        got2 = embt2.grad.cpu().numpy().astype(np.float32)
+        bad_want = ~np.isfinite(ge2.astype(np.float16).astype(np.float32))
+        assert bad_want.any() and np.array_equal(~np.isfinite(got2), bad_want)
     # frozen table
     xt2 = _t(x, device).requires_grad_(True)
     emb_frozen = _t(emb, device)
