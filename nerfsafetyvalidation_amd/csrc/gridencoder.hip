@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
                                                      bool align_corners, BinLevels bl, uint32_t first, BinPlan plan) {
     constexpr int C = 2, NC = 1 << D;
     constexpr uint32_t RC = MERGE ? NT * NC / 2 : NT * NC;          // staged records
-    static_assert(!MERGE || NT >= (int)kMergeSlots, "one thread per table slot");
+    constexpr int TPS = MERGE ? (int)((kMergeSlots + NT - 1) / NT) : 1;     // table slots per thread
     extern __shared__ uint2 rec[];                       // [RC] records sorted by bin (+ MERGE: table keys [kMergeSlots], sums [kMergeSlots][2])
     uint32_t* tkey = reinterpret_cast<uint32_t*>(rec + RC);
     unsigned long long* tval = reinterpret_cast<unsigned long long*>(tkey + kMergeSlots);
@@ -699,19 +699,25 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
             }
         }
     }
-    uint32_t tk = kMergeEmpty, tr = 0, tv = 0;            // MERGE: the table slot this thread turns into a record
+    uint32_t tk[TPS], tr[TPS], tv[TPS];                   // MERGE: the table slots this thread turns into records
+#pragma unroll
+    for (int j = 0; j < TPS; j++) { tk[j] = kMergeEmpty; tr[j] = 0; tv[j] = 0; }
     if (MERGE) {
         __syncthreads();
-        if (threadIdx.x < kMergeSlots && tkey[threadIdx.x] != kMergeEmpty) {
-            const float s0 = (float)(long long)tval[2 * threadIdx.x] * kMergeInvScale, s1 = (float)(long long)tval[2 * threadIdx.x + 1] * kMergeInvScale;
-            tv = to_half2(s0, s1);
-            const uint32_t k19 = tkey[threadIdx.x];
-            if (nonfinite(tv)) {                          // the merged sum left the fp16 range: the table entry becomes inf, as in the reference
-                const float vv[2] = {s0, s1};
-                table_add<_Float16, C>(tab, entry_of(k19 >> kBinLog, k19 & (kBinEntries - 1), hashed), vv);
-            } else if (tv & 0x7FFF7FFFu) {                // (sums that cancelled or rounded to zero add nothing)
-                tk = k19;
-                tr = atomicAdd(&cnt[tk >> kBinLog], 1u);
+#pragma unroll
+        for (int j = 0; j < TPS; j++) {
+            const uint32_t sl = threadIdx.x + j * NT;
+            if (sl < kMergeSlots && tkey[sl] != kMergeEmpty) {
+                const float s0 = (float)(long long)tval[2 * sl] * kMergeInvScale, s1 = (float)(long long)tval[2 * sl + 1] * kMergeInvScale;
+                tv[j] = to_half2(s0, s1);
+                const uint32_t k19 = tkey[sl];
+                if (nonfinite(tv[j])) {                   // the merged sum left the fp16 range: the table entry becomes inf, as in the reference
+                    const float vv[2] = {s0, s1};
+                    table_add<_Float16, C>(tab, entry_of(k19 >> kBinLog, k19 & (kBinEntries - 1), hashed), vv);
+                } else if (tv[j] & 0x7FFF7FFFu) {         // (sums that cancelled or rounded to zero add nothing)
+                    tk[j] = k19;
+                    tr[j] = atomicAdd(&cnt[k19 >> kBinLog], 1u);
+                }
             }
         }
     }
@@ -747,7 +753,11 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
 #pragma unroll
         for (int idx = 0; idx < NC; idx++)
             if (key[idx] != kMergeEmpty) place(key[idx] & ((1u << 19) - 1), key[idx] >> 19, val[idx]);
-        if (MERGE && tk != kMergeEmpty) place(tk, tr, tv);
+        if (MERGE) {
+#pragma unroll
+            for (int j = 0; j < TPS; j++)
+                if (tk[j] != kMergeEmpty) place(tk[j], tr[j], tv[j]);
+        }
         __syncthreads();
         const uint32_t n_win = total - base < RC ? total - base : RC;
         for (uint32_t i = threadIdx.x; i < n_win; i += NT) {
@@ -845,6 +855,9 @@ static bool g4_off() {                                   // diagnostics (NGP_GRI
     static const bool off = getenv("NGP_GRID_NO_G4") != nullptr;
     return off;
 }
+#ifndef NGP_BIN_NT
+#define NGP_BIN_NT 1024
+#endif
 constexpr uint32_t kMergeMaxRes = 1024;                   // levels up to this resolution merge across the rays of a workgroup (k_grid_bwd_bin<MERGE>)
 static uint32_t merge_max_res() {                        // (NGP_GRID_MERGE_RES overrides the threshold: diagnostics)
     static const uint32_t v = getenv("NGP_GRID_MERGE_RES") ? (uint32_t)atoi(getenv("NGP_GRID_MERGE_RES")) : kMergeMaxRes;
@@ -981,7 +994,7 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         group = group < n_bin ? group : n_bin;
         char* ws = group ? (char*)workspace : nullptr;
         if (ws) {
-            constexpr uint32_t NT = 1024;
+            constexpr uint32_t NT = NGP_BIN_NT;
             const uint32_t n_pb = div_up(B, NT);
             const size_t lds_bin = (size_t)NT * (1u << D) * sizeof(uint2);
             const size_t lds_merge = lds_bin / 2 + (size_t)kMergeSlots * (sizeof(uint32_t) + 2 * sizeof(unsigned long long));
