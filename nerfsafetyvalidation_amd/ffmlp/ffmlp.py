@@ -110,7 +110,10 @@ class FFMLP(nn.Module):
     def forward(self, inputs):
         """inputs [B, input_dim] -> [B, output_dim]"""
         B, C = inputs.shape
-        pad = 128 - (B % 128)  # F11: always pads 1..128 rows
+        # The reference pads to the next multiple of 128 and ALWAYS adds rows (ffmlp.py:156-158, SURVEY F11): a copy of the whole
+        # input per call (1.9 GB for a full-frame training batch).  Padding rows are zero inputs with zero gradients -- they reach no
+        # output row and no weight gradient -- and these kernels work on tiles of 16 rows, so only a ragged tail is padded.
+        pad = (-B) % 16
         if pad > 0:
             inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
         outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,

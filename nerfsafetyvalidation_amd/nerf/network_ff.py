@@ -30,6 +30,10 @@ class NeRFNetwork(NeRFRenderer):
 
     def _color_input(self, d, geo_feat):
         d = self.encoder_dir(d)
+        if d.dtype != geo_feat.dtype and geo_feat.dtype == torch.float16:
+            # the SH values are fp32, the geometry features fp16 (autocast): the reference's cat promotes all 32 columns to fp32
+            # and the FFMLP casts them back (network_ff.py:66-69, ffmlp.py:18) -- rounding the SH values first gives the same halves
+            d = d.to(torch.float16)
         p = torch.zeros_like(geo_feat[..., :1])
         return torch.cat([d, geo_feat, p], dim=-1)
 
