@@ -689,6 +689,85 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
     }
 }
 
+// The same computation with the samples of a tile taken ACROSS sixteen neighbouring rays (consecutive pixels of a row) at one
+// depth index instead of along one ray: neighbouring pixels at equal depth are ~4x closer than consecutive samples of a ray
+// (d / 1111 against span / 512), so the sixteen samples of a tile share cells -- and cache lines -- down to finer levels, as the
+// tiles of k_render_iter do; and the transmittance becomes a per-lane running product (no in-tile scan).  Lane c of every quarter
+// walks ray 16 g + c; a ray whose transmittance is spent idles until the last ray of its group is (neighbouring pixels end at
+// similar depths).  Per-sample granularity of the stop: a ray ends after the first sample that leaves carry < 1e-10.
+template <int MODE>
+__global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
+                                                               const float* __restrict__ rays_d, const float* __restrict__ nears,
+                                                               const float* __restrict__ fars, uint32_t N, uint32_t T,
+                                                               const float* __restrict__ lin, float* __restrict__ weights_sum,
+                                                               float* __restrict__ depth, float* __restrict__ image,
+                                                               float* __restrict__ aggregated_density, uint32_t dump_begin,
+                                                               float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_groups = (N + 15) / 16;
+    for (uint32_t grp = wave; grp < n_groups; grp += n_waves) {
+        const uint32_t ray_raw = grp * 16 + c;
+        const bool live = ray_raw < N;
+        const uint32_t ray = live ? ray_raw : N - 1;
+        const float ox = rays_o[(size_t)ray * 3], oy = rays_o[(size_t)ray * 3 + 1], oz = rays_o[(size_t)ray * 3 + 2];
+        const float dx = rays_d[(size_t)ray * 3], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
+        const float near = nears[ray], far = fars[ray];
+        const float span = far - near;
+        const float sample_dist = span * (1.0f / (float)T);                          // :153
+        const bool dump = live && sigmas != nullptr && ray >= dump_begin;
+        float carry = 1.0f;
+        float a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;
+        bool running = live;
+        float zv = near + span * lin[0];                                             // :150
+        for (uint32_t i = 0; i < T; i++) {
+            const float z_next = (i + 1 < T) ? near + span * lin[i + 1] : 0.0f;
+            const float x = clampf(ox + dx * zv, aabb_lo, aabb_hi);                  // :159-160
+            const float y = clampf(oy + dy * zv, aabb_lo, aabb_hi);
+            const float z = clampf(oz + dz * zv, aabb_lo, aabb_hi);
+            float sigma;
+            _Float16 s16[4];
+            net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+            // (quarter 0 holds sigma; the other quarters evaluate other rows of the sigma net in `sigma` and follow quarter 0's
+            //  decisions through the ballots below)
+            const float delta = (i + 1 < T) ? z_next - zv : sample_dist;             // :206-207
+            const float alpha = 1.0f - expf(((-delta) * na.density_scale) * sigma);  // :208
+            const float w = alpha * carry;                                           // :210
+            const bool counted = running && lane < 16;
+            const bool masked = counted && w > 1e-4f;                                // :216
+            float cr = 0, cg = 0, cb = 0;
+            if (__ballot(masked) != 0ull) {
+                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                if (!masked) { cr = 0; cg = 0; cb = 0; }
+            }
+            if (counted) {
+                a_ws += w;
+                const float qz = (zv - near) / span;                                 // :227
+                a_dep += w * (qz != qz ? qz : fminf(1.0f, fmaxf(0.0f, qz)));
+                a_r += w * cr; a_g += w * cg; a_b += w * cb;                         // :231
+                a_agg += w * sigma;                                                  // :244
+                if (dump) {
+                    const size_t row = (size_t)(ray - dump_begin) * T + i;
+                    sigmas[row] = sigma;
+                    rgbs[row * 3] = cr; rgbs[row * 3 + 1] = cg; rgbs[row * 3 + 2] = cb;
+                }
+                carry *= (1.0f - alpha) + 1e-15f;                                    // :209
+                if (!dump && carry < 1e-10f) running = false;                        // what follows is weighted by <= carry
+            }
+            if (__ballot(running && lane < 16) == 0ull) break;
+            zv = z_next;
+        }
+        if (lane < 16 && live) {
+            weights_sum[ray] = a_ws; depth[ray] = a_dep; aggregated_density[ray] = a_agg;
+            image[(size_t)ray * 3] = a_r; image[(size_t)ray * 3 + 1] = a_g; image[(size_t)ray * 3 + 2] = a_b;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NeRFRenderer.run WITH the NeRF-style importance resampling (nerf/renderer.py:172-204, sample_pdf :12-46), evaluation mode
 // (`det`: the u of the inverse-CDF draw are the fixed linspace of :26).  One wave walks one ray; everything the reference keeps
@@ -2496,6 +2575,26 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     uint32_t blocks = div_up(N, 4);
     if (blocks > 1024) blocks = 1024;   // 4 workgroups of 4 waves per CU; each wave strides over rays
     ProfScope prof("render_uniform", s, (double)N * T);
+    // tiles across sixteen neighbouring rays (twice the per-sample rate) once there are enough groups of sixteen to occupy the chip;
+    // a pose-estimator batch (1024 scattered pixels, every ray dumped) keeps one ray per wave
+    static const bool per_ray = getenv("NGP_UNIFORM_PER_RAY") != nullptr;     // diagnostics: tiles along one ray for every size
+    if (!per_ray && N >= 65536u) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<0>), 96 * 1024);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<1>), 96 * 1024);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<2>), 96 * 1024);
+        uint32_t gb = div_up(div_up(N, 16), 4);
+        if (gb > 1024) gb = 1024;
+        if (needs_generic(lv))
+            k_render_uniform_x16<1><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound);
+        else if (na.cells)
+            k_render_uniform_x16<2><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound);
+        else
+            k_render_uniform_x16<0><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound);
+        return check_launch("render_uniform");
+    }
     if (needs_generic(lv))
         k_render_uniform<1><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
                                                      dump_begin, sigmas, rgbs, -model->bound, model->bound);

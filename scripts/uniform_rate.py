@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Per-sample rate of ngp_render_uniform when no ray may stop early (every ray dumped: the F8 tensors of all rays are written) against
+the early-exit case, 800x800, T = 512."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nerfsafetyvalidation_amd.nerf.utils import get_rays
+from nerfsafetyvalidation_amd.scene import StonehengeScene
+from nerfsafetyvalidation_amd import raymarching
+dev = torch.device("cuda:0")
+sc = StonehengeScene(H=800, W=800, bound=2)
+model = sc.build_model(dev, cuda_ray=False)
+poses = torch.from_numpy(sc.poses).to(dev)
+fm = model.fused_model()
+with torch.no_grad():
+    r = get_rays(poses[3:4], sc.intrinsics, 800, 800)
+    o, d = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+    nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_infer, model.min_near)
+    N = o.shape[0]
+    for name, db, n in (("early exit", N, N), ("no exit (160k rays dumped)", 0, 160000)):
+        oo, dd, nn, ff = o[:n], d[:n], nears[:n], fars[:n]
+        fm.render_uniform(oo, dd, nn, ff, 512, min(db, n)); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): out = fm.render_uniform(oo, dd, nn, ff, 512, min(db, n))
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        print(name, "ms", round(dt * 1e3, 2), "nominal G samples/s", round(n * 512 / dt / 1e9, 2))
