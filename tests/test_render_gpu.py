@@ -297,6 +297,38 @@ def test_linear_backbone_fused_vs_operator_loop(device):
     assert abs(sa["iterations"] - sb["iterations"]) <= 2
 
 
+@pytest.mark.parametrize("backbone", ["ff", "linear"])
+def test_run_kernel_forms_agree(setup, device, backbone):
+    """ngp_render_uniform takes its tiles across sixteen neighbouring rays from 65 536 rays on (k_render_uniform_x16) and along one ray
+    below: the same 256x256 frame as one call and as two half calls -- per-sample tensors bit for bit, per-ray sums to fp32 summation
+    order, rays that miss the box included; a ragged ray count (not a multiple of 16) and rays that may not stop early (dump)."""
+    from nerfsafetyvalidation_amd import raymarching
+    sc = _scene(H=255, W=259)
+    model = sc.build_model(device, backbone=backbone, cuda_ray=False)
+    ro, rd = Hh.pinhole_rays(sc.poses[31], sc.intrinsics, sc.H, sc.W)
+    rd[100:140] = -rd[100:140]
+    o, d = _t(ro, device), _t(rd, device)
+    N = o.shape[0]
+    assert N >= 65536 + 16 and N % 16 != 0
+    T = 96
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        fm = model.fused_model()
+        nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_infer, model.min_near)
+        dump_begin = N - 3000
+        whole = fm.render_uniform(o, d, nears, fars, T, dump_begin)
+        h = 40000
+        a = fm.render_uniform(o[:h], d[:h], nears[:h], fars[:h], T, h)
+        b = fm.render_uniform(o[h:], d[h:], nears[h:], fars[h:], T, dump_begin - h)
+    for i, name in enumerate(("weights_sum", "depth", "image", "aggregated_density")):
+        x = whole[i].cpu().numpy()
+        y = np.concatenate([a[i].cpu().numpy(), b[i].cpu().numpy()])
+        assert np.array_equal(np.isnan(x), np.isnan(y))
+        err = np.abs(np.nan_to_num(x) - np.nan_to_num(y)).max()
+        assert err <= 2e-6 * max(1.0, np.abs(np.nan_to_num(y)).max()), (name, err)
+    assert torch.equal(whole[4], b[4]) and torch.equal(whole[5], b[5])       # sigmas, rgbs of the dumped rays
+    assert whole[4].shape[0] == 3000 * T
+
+
 @pytest.mark.parametrize("backbone,T,U", [("ff", 64, 48), ("linear", 128, 128), ("ff", 33, 7)])
 def test_run_path_importance_resampling_fused_vs_operators(setup, device, backbone, T, U):
     """NeRFRenderer.run with upsample_steps > 0 in evaluation mode: ONE fused launch (ngp_render_upsample: coarse pass, weights, CDF,
