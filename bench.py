@@ -22,6 +22,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak of the same guide (not the 2:1-sparsity headline)
+FLOP_PER_SAMPLE = 14336 + 22528              # sigma net 32-64-64-16 + colour net 32-64-64-64-16
 TABLE_BYTES_PER_SAMPLE = 16 * 8 * 4          # 16 levels x 8 corners x (2 x fp16): SURVEY 8d, the fused design's floor
 RAY_BYTES_PER_RAY_ITER = 4 + 24 + 8 + 2 * 20  # alive id + o,d + t,far + read-modify-write of (weights_sum, depth, rgb)
 
@@ -266,6 +268,9 @@ def main():
                         "traffic": pmc_traffic_per_launch(), "traffic_unit": f"bytes per launch (profiles/{PMC_SUMMARY}: FETCH_SIZE x2 + WRITE_SIZE)",
                         "achieved_bytes_per_launch": round(algo_bytes / n_launch.value), "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
                         "samples_per_s_in_kernel": round(units.value / (ms.value * 1e-3), 1),
+                        # the only dense contraction on the path: the two small MLPs (36,864 FLOP per sample) on the MFMA pipe
+                        "mfma": {"achieved": round(units.value * FLOP_PER_SAMPLE / (ms.value * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(units.value * FLOP_PER_SAMPLE / (ms.value * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
                         "measured_with": "one frame in flight (separate single-stream pass; rocprofv3 twin: `bench.py --in-flight 1`, "
                                          f"profiles/{KERNEL_STATS}).  With several frames in flight the streams' launches overlap "
                                          "and their durations are not additive",
