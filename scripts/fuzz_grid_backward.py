@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Table gradient of the hash-grid encoder (ngp_grid_encode_backward, fp16, two features) on random ray-ordered batches of random
+size, ray length, step and gradient sparsity, with regions of random capacity (overflow routes): every case against the oracle's
+scatter.  Usage: fuzz_grid_backward.py [seed] [cases]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import helpers as Hh
+from nerfsafetyvalidation_amd.gridencoder import grid_encode
+
+O = Hh.O
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+D, C, L = 3, 2, 16
+offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=19, desired_resolution=2048)
+bad = 0
+for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
+    T = int(rng.choice([1, 7, 64, 300]))
+    n_rays = int(rng.integers(131072 // T + 1, 260000 // T + 2))
+    step = float(rng.choice([0.0005, 0.002, 0.01]))
+    pct = rng.choice([None, 150, 60, 25, 5])
+    if pct is None: os.environ.pop("NGP_GRID_BIN_FILL_PCT", None)
+    else: os.environ["NGP_GRID_BIN_FILL_PCT"] = str(pct)
+    emb = rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32).astype(np.float16)
+    o = rng.uniform(0.2, 0.8, (n_rays, 1, 3))
+    d = rng.normal(size=(n_rays, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = (o + d * (np.arange(T) * step).reshape(1, T, 1)).reshape(-1, 3).astype(np.float32)
+    B = x.shape[0]
+    bad_rows = rng.integers(0, B, 20)
+    x[bad_rows] = rng.choice([1.5, -0.25, 1.0, 0.0], size=(20, 1))
+    g = (rng.normal(size=(B, L * C)) * 0.05).astype(np.float32).astype(np.float16)
+    g[rng.random(B) < rng.choice([0.0, 0.3, 0.9])] = 0          # points without a gradient
+    gl = np.ascontiguousarray(g.reshape(B, L, C).transpose(1, 0, 2))
+    want = np.zeros((offsets[-1], C), np.float32)
+    O.grid_encode_backward(gl.astype(np.float32), x, emb.astype(np.float32), offsets, want, B, D, C, L, float(np.log2(pls)), 16, False,
+                           np.zeros((B, L * D * C), np.float32), np.zeros((B, D), np.float32), 0, False)
+    embt = torch.from_numpy(emb).to(dev).requires_grad_(True)
+    grid_encode(torch.from_numpy(x).to(dev), embt, torch.from_numpy(offsets).to(dev), pls, 16, False, 0, False).backward(torch.from_numpy(g).to(dev))
+    got = embt.grad.cpu().numpy().astype(np.float32)
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max()
+    ok = err <= 8e-3 * scale + 2e-3
+    bad += not ok
+    print(f"case {case}: B {B} T {T} step {step} fill_pct {pct}: max err {err:.3e} (scale {scale:.3f}) {'ok' if ok else 'BAD'}")
+print("bad", bad)
+sys.exit(1 if bad else 0)

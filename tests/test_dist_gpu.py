@@ -59,6 +59,14 @@ def test_training_steps_on_two_threads_while_a_third_renders(device):
     assert "bad 0" in out.stdout
 
 
+def test_table_gradient_fuzz_against_the_oracle(device):
+    """scripts/fuzz_grid_backward.py: the two-pass table-gradient scatter on random ray-ordered batches (size, ray length, step, share
+    of zero gradients, out-of-range rows) with regions sized for 5-150 % of the updates: every case against the oracle's scatter."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_grid_backward.py"), "2", "6"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "bad 0" in out.stdout
+
+
 def test_full_200_view_sweep_through_a_one_rank_rccl_group(device):
     """BASELINE configs[2] at full size -- all 200 views of the validation sweep at 800x800 -- on this box's one GPU, once without a
     process group and once through a ONE-RANK `nccl` (= RCCL) group with the tile all_gathers really issued: RCCL is loaded and
