@@ -129,6 +129,9 @@ def rollout_main(args):
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"Monte-Carlo stress-test rollout (BASELINE configs[4]): {n_sims} simulations x {args.steps} steps, per step 2 "
                                    f"renders of {H}x{W} through NeRFRenderer.run (512 uniform samples per ray) + Gaussian-approximation UQ",
+                       "samples_counted": "nominal: rays x 512 per frame, as the reference's run evaluates them; the fused kernel stops "
+                                          "evaluating a ray once its transmittance is below 1e-10 (about an eighth of the nominal samples "
+                                          "of these frames are evaluated; without early stops the kernel does 8.3 G samples/s)",
                        "simulations": n_sims, "simulations_in_flight_per_gpu": args.in_flight,
                        "parallelism": f"simulations sharded x{world}, one all_gather of the CSV rows at the end" if world > 1 else "single GPU"},
             "frames_per_sec": round(frames / elapsed, 3), "simulator_steps_per_sec": round(frames / 2 / elapsed, 3),
