@@ -329,7 +329,7 @@ def test_run_kernel_forms_agree(setup, device, backbone):
     assert whole[4].shape[0] == 3000 * T
 
 
-@pytest.mark.parametrize("backbone,T,U", [("ff", 64, 48), ("linear", 128, 128), ("ff", 33, 7)])
+@pytest.mark.parametrize("backbone,T,U", [("ff", 64, 48), ("linear", 128, 128), ("ff", 33, 7), ("ff", 512, 512), ("linear", 1024, 1000)])
 def test_run_path_importance_resampling_fused_vs_operators(setup, device, backbone, T, U):
     """NeRFRenderer.run with upsample_steps > 0 in evaluation mode: ONE fused launch (ngp_render_upsample: coarse pass, weights, CDF,
     inverse-CDF draw, fine pass, merge, compositing, all in LDS) against the operator chain of nerf/sampling.py on the same fp16
