@@ -787,12 +787,14 @@ def test_fused_run_gradient_golden_and_guards(device):
     assert np.isfinite(gp3).all()
 
 
-def test_run_path_exit_is_taken_by_whole_waves(device):
+@pytest.mark.parametrize("H,W", [(20, 20), (256, 257)], ids=["one_ray_per_wave", "tiles_across_rays"])
+def test_run_path_exit_is_taken_by_whole_waves(device, H, W):
     """k_render_uniform's early exit (transmittance below 1e-10) must be decided by the ray's own transmittance for the whole wave.
     Lanes 16..63 of a tile hold OTHER rows of the sigma net where quarter 0 holds sigma; with large geo features their private
     products collapse at once, and a quarter that left the loop on them would stop gathering its levels for the samples still to
-    come.  (The random-init network of the other tests has geo features near 0, which hid exactly that.)"""
-    sc = _scene(H=20, W=20)
+    come.  (The random-init network of the other tests has geo features near 0, which hid exactly that.)  Both forms of the kernel:
+    one ray per wave (small batches) and tiles across sixteen rays (from 65 536 rays on), where only quarter 0's lanes carry a ray."""
+    sc = _scene(H=H, W=W)
     model = sc.build_model(device, cuda_ray=False)
     with torch.no_grad():
         blob = model.sigma_net.weights.view(-1)
