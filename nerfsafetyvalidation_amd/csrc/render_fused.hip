@@ -695,6 +695,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
 // tiles of k_render_iter do; and the transmittance becomes a per-lane running product (no in-tile scan).  Lane c of every quarter
 // walks ray 16 g + c; a ray whose transmittance is spent idles until the last ray of its group is (neighbouring pixels end at
 // similar depths).  Per-sample granularity of the stop: a ray ends after the first sample that leaves carry < 1e-10.
+constexpr uint32_t kUniformX16MinRays = 65536;      // (measured: section 4 of DESIGN.md)
 template <int MODE>
 __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
                                                                const float* __restrict__ rays_d, const float* __restrict__ nears,
@@ -2578,7 +2579,8 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     // tiles across sixteen neighbouring rays (twice the per-sample rate) once there are enough groups of sixteen to occupy the chip;
     // a pose-estimator batch (1024 scattered pixels, every ray dumped) keeps one ray per wave
     static const bool per_ray = getenv("NGP_UNIFORM_PER_RAY") != nullptr;     // diagnostics: tiles along one ray for every size
-    if (!per_ray && N >= 65536u) {
+    static const uint32_t x16_min = getenv("NGP_UNIFORM_X16_MIN") ? (uint32_t)atoi(getenv("NGP_UNIFORM_X16_MIN")) : kUniformX16MinRays;
+    if (!per_ray && N >= x16_min) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<0>), 96 * 1024);
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<1>), 96 * 1024);
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<2>), 96 * 1024);
