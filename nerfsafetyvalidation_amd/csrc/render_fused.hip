@@ -2578,8 +2578,8 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     ProfScope prof("render_uniform", s, (double)N * T);
     // tiles across sixteen neighbouring rays (twice the per-sample rate) once there are enough groups of sixteen to occupy the chip;
     // a pose-estimator batch (1024 scattered pixels, every ray dumped) keeps one ray per wave
-    static const bool per_ray = getenv("NGP_UNIFORM_PER_RAY") != nullptr;     // diagnostics: tiles along one ray for every size
-    static const uint32_t x16_min = getenv("NGP_UNIFORM_X16_MIN") ? (uint32_t)atoi(getenv("NGP_UNIFORM_X16_MIN")) : kUniformX16MinRays;
+    const bool per_ray = getenv("NGP_UNIFORM_PER_RAY") != nullptr;            // diagnostics (read per call): tiles along one ray for every size
+    const uint32_t x16_min = getenv("NGP_UNIFORM_X16_MIN") ? (uint32_t)atoi(getenv("NGP_UNIFORM_X16_MIN")) : kUniformX16MinRays;
     if (!per_ray && N >= x16_min) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<0>), 96 * 1024);
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<1>), 96 * 1024);

@@ -297,6 +297,51 @@ def test_linear_backbone_fused_vs_operator_loop(device):
     assert abs(sa["iterations"] - sb["iterations"]) <= 2
 
 
+def test_run_full_size_frame_properties(setup, device, monkeypatch):
+    """BASELINE configs[4]'s frame -- 800x800 through `run` with 512 samples per ray, what every rollout step renders twice -- checked
+    through properties: (a) the two forms of the kernel (tiles across sixteen rays / along one ray) give the same frame, per-sample
+    tensors of the last chunk bit for bit, per-ray sums to fp32 summation order; (b) rays are independent: a strip of rows rendered
+    on its own gives the same pixels bit for bit (the sums of a ray run over its own samples in order whatever its neighbours are);
+    (c) ranges; (d) determinism; (e) every 997th ray against the CPU oracle's `run` within the fp16 network's tolerance."""
+    sc = _scene(H=800, W=800)
+    model = sc.build_model(device, cuda_ray=False)
+    net = Hh.OracleNetwork.from_torch(model)
+    ro, rd = Hh.pinhole_rays(sc.poses[12], sc.intrinsics, sc.H, sc.W)
+    o, d = _t(ro, device)[None], _t(rd, device)[None]
+    kw = dict(staged=True, max_ray_batch=4096, bg_color=1, perturb=False, num_steps=512, upsample_steps=0)
+
+    def render(oo=o, dd=d):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            r = model.render(oo, dd, **kw)
+        return {k: r[k].float() for k in ("image", "depth", "aggregated_density", "rgbs", "sigmas")}
+
+    full = render()
+    again = render()
+    monkeypatch.setenv("NGP_UNIFORM_PER_RAY", "1")
+    along = render()
+    monkeypatch.delenv("NGP_UNIFORM_PER_RAY")
+    # (a)
+    assert torch.equal(full["rgbs"], along["rgbs"]) and torch.equal(full["sigmas"], along["sigmas"])
+    for k in ("image", "depth", "aggregated_density"):
+        assert float((full[k] - along[k]).abs().max()) <= 2e-6 * max(1.0, float(along[k].abs().max())), k
+    # (b) rows 300..339 on their own: 32000 rays -> the one-ray-per-wave form, and different groups of sixteen in any case
+    lo, hi = 300 * 800, 340 * 800
+    strip = render(o[:, lo:hi], d[:, lo:hi])
+    for k in ("image", "depth", "aggregated_density"):
+        assert float((strip[k][0] - full[k][0, lo:hi]).abs().max()) <= 2e-6, k
+    # (c), (d)
+    assert float(full["image"].min()) >= 0.0 and float(full["image"].max()) <= 1.0 + 1e-5
+    assert float(full["depth"].min()) >= 0.0 and float(full["depth"].max()) <= 1.0 + 1e-5
+    for k in full:
+        assert torch.equal(full[k], again[k]), k
+    # (e)
+    idx = np.arange(0, ro.shape[0], 997)
+    want = Hh.oracle_run(net, ro[idx], rd[idx], sc.bound, sc.density_scale, 512)
+    err = np.abs(full["image"][0].cpu().numpy()[idx] - want["image"])
+    print(f"run 800x800, every 997th ray vs oracle: max |dRGB| {err.max():.2e} mean {err.mean():.2e}")
+    assert err.max() < 2.5e-4 and err.mean() < 1e-5          # 2 x the observed 1.0e-4 / 4.5e-6
+
+
 @pytest.mark.parametrize("backbone", ["ff", "linear"])
 def test_run_kernel_forms_agree(setup, device, backbone):
     """ngp_render_uniform takes its tiles across sixteen neighbouring rays from 65 536 rays on (k_render_uniform_x16) and along one ray
