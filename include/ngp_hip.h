@@ -296,7 +296,9 @@ NGP_API int ngp_network_density(const ngp_model* model, const float* xyzs, uint3
 NGP_API int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears,
                        const float* fars, uint32_t N, uint32_t T, const float* lin, float* weights_sum, float* depth,
                        float* image, float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs,
-                       ngp_stream_t stream);
+                       uint32_t frame_width, ngp_stream_t stream);
+/* frame_width: optional scheduling hint (0 = none) as in ngp_render_ctx_set_frame_width -- the rays are the pixels of row-major
+ * frames this wide, so the kernel can take its groups of sixteen rays as 4x4-pixel blocks.  Results do not depend on it. */
 
 /* The same with the NeRF-style importance resampling of nerf/renderer.py:172-204 in evaluation mode (sample_pdf :12-46 with det=True):
  * T uniform samples, U more drawn from the piecewise-constant PDF of the coarse weights (u = the U values of

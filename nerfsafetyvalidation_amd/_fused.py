@@ -25,9 +25,9 @@ class RunUniform(torch.autograd.Function):
     (ngp_render_uniform_backward) -- differentiable in the rays, the map frozen: the pose gradients of the state estimator."""
 
     @staticmethod
-    def forward(ctx, fm, rays_o, rays_d, nears, fars, num_steps, dump_begin):
+    def forward(ctx, fm, rays_o, rays_d, nears, fars, num_steps, dump_begin, frame_width=0):
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
-        ws, depth, image, agg, sigmas, rgbs = fm.render_uniform(rays_o, rays_d, nears, fars, num_steps, dump_begin)
+        ws, depth, image, agg, sigmas, rgbs = fm.render_uniform(rays_o, rays_d, nears, fars, num_steps, dump_begin, frame_width)
         ctx.fm, ctx.num_steps = fm, num_steps
         ctx.save_for_backward(rays_o, rays_d, nears, fars)
         ctx.mark_non_differentiable(sigmas, rgbs)
@@ -38,7 +38,7 @@ class RunUniform(torch.autograd.Function):
         rays_o, rays_d, nears, fars = ctx.saved_tensors
         zeros = g_image if g_image is not None else torch.zeros(rays_o.shape[0], 3, device=rays_o.device)
         go, gd = ctx.fm.render_uniform_backward(rays_o, rays_d, nears, fars, ctx.num_steps, zeros, g_depth, g_ws, g_agg)
-        return None, go, gd, None, None, None, None
+        return None, go, gd, None, None, None, None, None
 
 
 def _versions(tensors):
@@ -244,9 +244,10 @@ class FusedModel:
             sigmas, rgbs = last_s[:M], last_c[:M]
         return weights_sum, depth, image, sigmas, rgbs
 
-    def render_uniform(self, rays_o, rays_d, nears, fars, num_steps, dump_begin):
+    def render_uniform(self, rays_o, rays_d, nears, fars, num_steps, dump_begin, frame_width=0):
         """NeRFRenderer.run without upsampling for ALL rays in one launch -> weights_sum, depth, image (no background), aggregated
-        density [N] and the per-sample sigmas [(N-dump_begin)*T, 1] / rgbs [N-dump_begin, T, 3] of the rays >= dump_begin"""
+        density [N] and the per-sample sigmas [(N-dump_begin)*T, 1] / rgbs [N-dump_begin, T, 3] of the rays >= dump_begin.
+        frame_width: the rays are the pixels of row-major frames this wide (scheduling hint, results do not depend on it)"""
         self._ensure_cells()
         N, T, dev = rays_o.shape[0], int(num_steps), rays_o.device
         lin = torch.linspace(0.0, 1.0, T, device=dev)
@@ -259,7 +260,7 @@ class FusedModel:
         lib = _lib.lib()
         _lib.check(lib.ngp_render_uniform(C.byref(m), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()), _lib.ptr(fars.contiguous()),
                                           N, T, _lib.ptr(lin), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
-                                          dump_begin, _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.stream()), "render_uniform")
+                                          dump_begin, _lib.ptr(sigmas), _lib.ptr(rgbs), int(frame_width or 0), _lib.stream()), "render_uniform")
         return out[0], out[1], out[2], out[3], sigmas, rgbs
 
     def upsample_fits(self, num_steps, upsample_steps):

@@ -98,7 +98,7 @@ SIGNATURES = {
     "ngp_density_grid_workspace": [_u32, _u32],
     "ngp_density_grid_update": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _f32, _f32, _vp, _sz, _vp],
     "ngp_density_grid_finish": [_vp, _u32, _u32, _f32, _vp, _vp, _vp, _sz, _vp],
-    "ngp_render_uniform": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
+    "ngp_render_uniform": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
     "ngp_render_upsample": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
     "ngp_debug_set_stamps": [_vp],
     "ngp_debug_set_sample_hash": [_vp],

@@ -703,7 +703,8 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
                                                                const float* __restrict__ lin, float* __restrict__ weights_sum,
                                                                float* __restrict__ depth, float* __restrict__ image,
                                                                float* __restrict__ aggregated_density, uint32_t dump_begin,
-                                                               float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi) {
+                                                               float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi,
+                                                               uint32_t frame_w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
@@ -712,7 +713,11 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_groups = (N + 15) / 16;
     for (uint32_t grp = wave; grp < n_groups; grp += n_waves) {
-        const uint32_t ray_raw = grp * 16 + c;
+        uint32_t ray_raw = grp * 16 + c;
+        if (frame_w) {      // 4x4-pixel blocks of row-major frames `frame_w` wide (frame_w % 4 == 0, N % (4 * frame_w) == 0: checked on the host)
+            const uint32_t bpr = frame_w >> 2, by = grp / bpr, bx = grp - by * bpr;
+            ray_raw = (by * 4 + (c >> 2)) * frame_w + bx * 4 + (c & 3);
+        }
         const bool live = ray_raw < N;
         const uint32_t ray = live ? ray_raw : N - 1;
         const float ox = rays_o[(size_t)ray * 3], oy = rays_o[(size_t)ray * 3 + 1], oz = rays_o[(size_t)ray * 3 + 2];
@@ -2556,7 +2561,7 @@ int ngp_pack_weights(const ngp_model* model, void* out, ngp_stream_t stream) {
 
 int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N,
                        uint32_t T, const float* lin, float* weights_sum, float* depth, float* image, float* aggregated_density,
-                       uint32_t dump_begin, float* sigmas, float* rgbs, ngp_stream_t stream) {
+                       uint32_t dump_begin, float* sigmas, float* rgbs, uint32_t frame_width, ngp_stream_t stream) {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && nears && fars && lin && weights_sum && depth && image && aggregated_density, "render_uniform: null pointer");
     NGP_REQUIRE((sigmas == nullptr) == (rgbs == nullptr), "render_uniform: sigmas and rgbs must both be given or both NULL");
@@ -2584,17 +2589,21 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<0>), 96 * 1024);
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<1>), 96 * 1024);
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<2>), 96 * 1024);
+        // frame_width (scheduling hint, results do not depend on it): the rays are the pixels of row-major frames this wide -> a
+        // group is a 4x4-pixel block instead of a 1x16 strip (its sixteen rays are closer together and end at more similar depths)
+        uint32_t fw = frame_width;
+        if (fw && (fw % 4 != 0 || N % (4 * fw) != 0)) fw = 0;
         uint32_t gb = div_up(div_up(N, 16), 4);
         if (gb > 1024) gb = 1024;
         if (needs_generic(lv))
             k_render_uniform_x16<1><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw);
         else if (na.cells)
             k_render_uniform_x16<2><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw);
         else
             k_render_uniform_x16<0><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw);
         return check_launch("render_uniform");
     }
     if (needs_generic(lv))

@@ -352,7 +352,7 @@ class NeRFRenderer(nn.Module):
             if upsample_steps > 0:      # importance resampling (evaluation mode, no gradients: the caller checked)
                 ws, dep, img, ag, sigmas, rgbs = fm.render_upsample(o, d, nears, fars, int(num_steps), int(upsample_steps), last_begin)
             else:
-                ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin)
+                ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin, int(kwargs.get("frame_width", 0) or 0))
             img = img + (1 - ws).unsqueeze(-1) * (1 if bg_color is None else bg_color)
             depth.append(dep), image.append(img), agg.append(ag)
         return {"depth": torch.stack(depth, 0), "image": torch.stack(image, 0), "rgbs": rgbs, "sigmas": sigmas,

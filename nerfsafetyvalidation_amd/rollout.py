@@ -165,7 +165,8 @@ class RolloutSimulator:
         from .uncertainty.quantification.gaussian_approximation_density_uncertainty import GaussianApproximationDensityUncertainty
         self.model, self.intrinsics, self.H, self.W, self.steps, self.seed = model, intrinsics, H, W, steps, seed
         self.device = next(model.parameters()).device if model is not None else None
-        self.render_kwargs = dict(staged=True, bg_color=1.0, perturb=False)
+        # frame_width: scheduling hint of this build's renderer (the rays are whole row-major frames); results do not depend on it
+        self.render_kwargs = dict(staged=True, bg_color=1.0, perturb=False, frame_width=W)
         self.render_kwargs.update(render_kwargs or {})
         self.n_interp = num_interpolated_points
         self.renders_per_step = renders_per_step

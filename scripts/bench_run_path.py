@@ -25,7 +25,7 @@ for backbone, (T, U) in [(b, c) for b in ("linear", "ff") for c in CASES]:
             def frame(v):
                 r = get_rays(poses[v:v + 1], sc.intrinsics, H, W)
                 return model.render(r["rays_o"], r["rays_d"], staged=True, max_ray_batch=4096, bg_color=1, perturb=False, num_steps=T,
-                                    upsample_steps=U)
+                                    upsample_steps=U, frame_width=W)
             frame(0); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(reps): out = frame(1 + i)

@@ -17,10 +17,11 @@ with torch.no_grad():
     o, d = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
     nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_infer, model.min_near)
     N = o.shape[0]
-    for name, db, n in (("early exit", N, N), ("no exit (160k rays dumped)", 0, 160000)):
-        oo, dd, nn, ff = o[:n], d[:n], nears[:n], fars[:n]
-        fm.render_uniform(oo, dd, nn, ff, 512, min(db, n)); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3): out = fm.render_uniform(oo, dd, nn, ff, 512, min(db, n))
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-        print(name, "ms", round(dt * 1e3, 2), "nominal G samples/s", round(n * 512 / dt / 1e9, 2))
+    for fw in (0, 800):          # groups of sixteen rays as 1x16 strips / as 4x4-pixel blocks (the frame-width hint)
+        for name, db, n in (("early exit", N, N), ("no exit (160k rays = 200 rows dumped)", 0, 160000)):
+            oo, dd, nn, ff = o[:n], d[:n], nears[:n], fars[:n]
+            fm.render_uniform(oo, dd, nn, ff, 512, min(db, n), fw); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3): out = fm.render_uniform(oo, dd, nn, ff, 512, min(db, n), fw)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+            print("frame_width", fw, name, "ms", round(dt * 1e3, 2), "nominal G samples/s", round(n * 512 / dt / 1e9, 2))

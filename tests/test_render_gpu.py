@@ -317,6 +317,13 @@ def test_run_full_size_frame_properties(setup, device, monkeypatch):
 
     full = render()
     again = render()
+    # the frame-width hint regroups the rays into 4x4-pixel blocks: every ray's sums run over its own samples in order, whatever its
+    # fifteen neighbours are -> the same bits
+    kw["frame_width"] = 800
+    blocks = render()
+    del kw["frame_width"]
+    for k in full:
+        assert torch.equal(full[k], blocks[k]), k
     monkeypatch.setenv("NGP_UNIFORM_PER_RAY", "1")
     along = render()
     monkeypatch.delenv("NGP_UNIFORM_PER_RAY")
