@@ -39,7 +39,8 @@ def parse():
     p.add_argument("--profile-steps", type=int, default=3)
     p.add_argument("--debug-flags", type=int, default=0, help="ngp_debug_disable_march_queue flags (A/B experiments only)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the flow)")
-    p.add_argument("--in-flight", type=int, default=3, help="frames rendered concurrently per GPU, each by its own render call on its own stream "
+    p.add_argument("--in-flight", type=int, default=None, help="(default 3; rollout workload: all of a rank's simulations) "
+                   "frames rendered concurrently per GPU, each by its own render call on its own stream "
                                                            "(nerfsafetyvalidation_amd.pipeline.FramePipeline); 1 = strictly one after the other")
     p.add_argument("--batched-views", type=int, default=4, help="extra, untimed leg: cameras per render call (0 = skip); reported under 'batched'")
     p.add_argument("--no-last", action="store_true", help="do not materialise the last iteration's sigmas/rgbs tensors")
@@ -50,7 +51,10 @@ def parse():
                    help="N = 1 only: create a one-rank process group of --backend and run the per-step tile all_gather anyway (smoke test of "
                         "the RCCL path and its stream / event ordering on a one-GPU box; off by default: a single GPU has nothing to exchange)")
     p.add_argument("--sims-per-gpu", type=int, default=6, help="rollout: simulations per rank (weak scaling)")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.in_flight is None:
+        a.in_flight = a.sims_per_gpu if a.workload == "rollout" else 3
+    return a
 
 
 PMC_SUMMARY = "r02_pmc.json"                    # scripts/profile_round.sh, copied into profiles/ at the end of the round
