@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
                                                                float* __restrict__ depth, float* __restrict__ image,
                                                                float* __restrict__ aggregated_density, uint32_t dump_begin,
                                                                float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi,
-                                                               uint32_t frame_w) {
+                                                               uint32_t frame_w, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
@@ -729,8 +729,10 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
         float carry = 1.0f;
         float a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;
         bool running = live;
+        uint32_t n_iter = 0, n_counted = 0;
         float zv = near + span * lin[0];                                             // :150
         for (uint32_t i = 0; i < T; i++) {
+            n_iter++;
             const float z_next = (i + 1 < T) ? near + span * lin[i + 1] : 0.0f;
             const float x = clampf(ox + dx * zv, aabb_lo, aabb_hi);                  // :159-160
             const float y = clampf(oy + dy * zv, aabb_lo, aabb_hi);
@@ -751,6 +753,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
                 if (!masked) { cr = 0; cg = 0; cb = 0; }
             }
             if (counted) {
+                n_counted++;
                 a_ws += w;
                 const float qz = (zv - near) / span;                                 // :227
                 a_dep += w * (qz != qz ? qz : fminf(1.0f, fmaxf(0.0f, qz)));
@@ -770,6 +773,12 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
         if (lane < 16 && live) {
             weights_sum[ray] = a_ws; depth[ray] = a_dep; aggregated_density[ray] = a_agg;
             image[(size_t)ray * 3] = a_r; image[(size_t)ray * 3 + 1] = a_g; image[(size_t)ray * 3 + 2] = a_b;
+        }
+        if (stamps) {    // diagnostics (ngp_debug_set_stamps): depth indices walked by the group x 16 lanes, and those that carried a running ray
+            uint32_t mine = lane < 16 ? n_counted : 0u;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 16);
+            if (lane == 0) { atomicAdd(stamps + 12, (unsigned long long)n_iter * 16ull); atomicAdd(stamps + 13, (unsigned long long)mine); }
         }
     }
 }
@@ -2591,19 +2600,20 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<2>), 96 * 1024);
         // frame_width (scheduling hint, results do not depend on it): the rays are the pixels of row-major frames this wide -> a
         // group is a 4x4-pixel block instead of a 1x16 strip (its sixteen rays are closer together and end at more similar depths)
+        unsigned long long* dbg_stamps = debug_snapshot(nullptr).stamps;
         uint32_t fw = frame_width;
         if (fw && (fw % 4 != 0 || N % (4 * fw) != 0)) fw = 0;
         uint32_t gb = div_up(div_up(N, 16), 4);
         if (gb > 1024) gb = 1024;
         if (needs_generic(lv))
             k_render_uniform_x16<1><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps);
         else if (na.cells)
             k_render_uniform_x16<2><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps);
         else
             k_render_uniform_x16<0><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps);
         return check_launch("render_uniform");
     }
     if (needs_generic(lv))

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Lane utilisation of k_render_uniform_x16 (groups of sixteen rays walking the depth indices together): share of the lane-iterations
+that carried a ray still running, and share of a frame's nominal samples that is evaluated -- an orbit view and a rollout pose."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+from nerfsafetyvalidation_amd import _lib, raymarching, rollout as RO
+from nerfsafetyvalidation_amd.nerf.utils import get_rays
+from nerfsafetyvalidation_amd.scene import StonehengeScene
+dev = torch.device("cuda:0"); lib = _lib.lib()
+sc = StonehengeScene(H=800, W=800, bound=2)
+model = sc.build_model(dev, cuda_ray=False)
+fm = model.fused_model()
+poses = {"orbit view 3": torch.from_numpy(sc.poses[3:4]).to(dev)}
+st = RO.initial_state(20).numpy()
+poses["rollout pose"] = torch.from_numpy(np.asarray(RO.camera_pose(torch.from_numpy(st)), np.float32)[None]).to(dev)
+for name, pose in poses.items():
+    with torch.no_grad():
+        r = get_rays(pose, sc.intrinsics, 800, 800)
+        o, d = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+        nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_infer, model.min_near)
+        for fw in (0, 800):
+            buf = torch.zeros(16, dtype=torch.int64, device=dev)
+            lib.ngp_debug_set_stamps(buf.data_ptr())
+            fm.render_uniform(o, d, nears, fars, 512, o.shape[0], fw)
+            torch.cuda.synchronize(); lib.ngp_debug_set_stamps(None)
+            b = buf.cpu().tolist()
+            print(name, "frame_width", fw, "lane-iterations", b[12], "useful", b[13], "utilisation", round(b[13] / max(1, b[12]), 3), "evaluated share of nominal", round(b[12] / (640000 * 512), 3))
