@@ -308,7 +308,13 @@ NGP_API int ngp_render_uniform(const ngp_model* model, const float* rays_o, cons
 NGP_API int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears,
                         const float* fars, uint32_t N, uint32_t T, uint32_t U, const float* lin, const float* u,
                         float* weights_sum, float* depth, float* image, float* aggregated_density, uint32_t dump_begin,
-                        float* sigmas, float* rgbs, ngp_stream_t stream);
+                        float* sigmas, float* rgbs, uint32_t frame_width, void* workspace, size_t workspace_bytes,
+                        ngp_stream_t stream);
+/* frame_width: the scheduling hint of ngp_render_uniform.  workspace (optional, caller-owned device memory of
+ * ngp_render_upsample_workspace(N, T, U) bytes; 0 = this batch size does not use one): with it, large batches run as four
+ * launches -- both density passes and the merge + compositing with tiles across neighbouring rays, the resampling per ray in
+ * between -- instead of one launch per ray.  Same samples (bit-identical sigmas / rgbs), per-ray sums to fp32 summation order. */
+NGP_API size_t ngp_render_upsample_workspace(uint32_t N, uint32_t T, uint32_t U);
 
 /* Vector-Jacobian product of ngp_render_uniform with respect to the RAYS with the map (table, weights) frozen: what
  * nav/estimator_helpers.py:191-225 differentiates (pose gradients through get_rays -> render -> run, <= 1024 pixels x 512 samples).

@@ -268,9 +268,10 @@ class FusedModel:
         weights = 2 * ((2048 + self.sigma_mm * 4096 + 1024) + (2048 + self.color_mm * 4096 + 1024))
         return num_steps >= 3 and upsample_steps >= 1 and weights + 2048 + 4 * (5 * num_steps + 4 * upsample_steps) <= 159 * 1024
 
-    def render_upsample(self, rays_o, rays_d, nears, fars, num_steps, upsample_steps, dump_begin):
-        """NeRFRenderer.run with importance resampling (evaluation mode) for ALL rays in one launch; returns what render_uniform
-        returns, with T + U samples per ray in sigmas / rgbs"""
+    def render_upsample(self, rays_o, rays_d, nears, fars, num_steps, upsample_steps, dump_begin, frame_width=0):
+        """NeRFRenderer.run with importance resampling (evaluation mode) for ALL rays; returns what render_uniform returns, with
+        T + U samples per ray in sigmas / rgbs.  One launch; from 65 536 rays on four, the density passes with tiles across rays
+        (scratch from torch's allocator; frame_width: scheduling hint) -- the same bits either way"""
         self._ensure_cells()
         N, T, U, dev = rays_o.shape[0], int(num_steps), int(upsample_steps), rays_o.device
         lin = torch.linspace(0.0, 1.0, T, device=dev)
@@ -281,9 +282,13 @@ class FusedModel:
         sigmas = torch.empty(n_dump * (T + U), 1, dtype=torch.float32, device=dev)
         rgbs = torch.empty(n_dump, T + U, 3, dtype=torch.float32, device=dev)
         m = self._struct(None)
-        _lib.check(_lib.lib().ngp_render_upsample(C.byref(m), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()), _lib.ptr(fars.contiguous()),
-                                                  N, T, U, _lib.ptr(lin), _lib.ptr(u), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
-                                                  _lib.ptr(out[3]), dump_begin, _lib.ptr(sigmas), _lib.ptr(rgbs), _lib.stream()), "render_upsample")
+        lib = _lib.lib()
+        wbytes = lib.ngp_render_upsample_workspace(N, T, U)
+        work = torch.empty((wbytes + 3) // 4, dtype=torch.float32, device=dev) if wbytes else None
+        _lib.check(lib.ngp_render_upsample(C.byref(m), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(nears.contiguous()), _lib.ptr(fars.contiguous()),
+                                           N, T, U, _lib.ptr(lin), _lib.ptr(u), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
+                                           _lib.ptr(out[3]), dump_begin, _lib.ptr(sigmas), _lib.ptr(rgbs), int(frame_width or 0), _lib.ptr(work), wbytes,
+                                           _lib.stream()), "render_upsample")
         return out[0], out[1], out[2], out[3], sigmas, rgbs
 
     def render_uniform_backward(self, rays_o, rays_d, nears, fars, num_steps, g_image, g_depth=None, g_ws=None, g_agg=None):

@@ -99,7 +99,8 @@ SIGNATURES = {
     "ngp_density_grid_update": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _f32, _f32, _vp, _sz, _vp],
     "ngp_density_grid_finish": [_vp, _u32, _u32, _f32, _vp, _vp, _vp, _sz, _vp],
     "ngp_render_uniform": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
-    "ngp_render_upsample": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
+    "ngp_render_upsample": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _sz, _vp],
+    "ngp_render_upsample_workspace": [_u32, _u32, _u32],
     "ngp_debug_set_stamps": [_vp],
     "ngp_debug_set_sample_hash": [_vp],
     "ngp_debug_disable_march_queue": [_int],
@@ -111,7 +112,7 @@ SIGNATURES = {
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
 _RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_packed_weights_bwd_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
-             "ngp_ffmlp_backward_workspace": _sz, "ngp_ffmlp_backward_buffer_bytes": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
+             "ngp_ffmlp_backward_workspace": _sz, "ngp_ffmlp_backward_buffer_bytes": _sz, "ngp_render_upsample_workspace": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
 
 _lib = None
 

@@ -42,6 +42,7 @@ namespace ngp {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 8;                 // waves per workgroup
@@ -696,7 +697,9 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
 // walks ray 16 g + c; a ray whose transmittance is spent idles until the last ray of its group is (neighbouring pixels end at
 // similar depths).  Per-sample granularity of the stop: a ray ends after the first sample that leaves carry < 1e-10.
 constexpr uint32_t kUniformX16MinRays = 65536;      // (measured: section 4 of DESIGN.md)
-template <int MODE>
+// DENS: the density pass alone -- sigma of every uniform sample of every ray into sigmas [N, T], no colour, no sums, no early stop
+// (the coarse pass of the importance resampling, ngp_density_uniform).
+template <int MODE, bool DENS = false>
 __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
                                                                const float* __restrict__ rays_d, const float* __restrict__ nears,
                                                                const float* __restrict__ fars, uint32_t N, uint32_t T,
@@ -704,7 +707,8 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
                                                                float* __restrict__ depth, float* __restrict__ image,
                                                                float* __restrict__ aggregated_density, uint32_t dump_begin,
                                                                float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi,
-                                                               uint32_t frame_w, unsigned long long* __restrict__ stamps) {
+                                                               uint32_t frame_w, unsigned long long* __restrict__ stamps,
+                                                               const float* __restrict__ z_in, _Float16* __restrict__ geo_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
@@ -730,6 +734,25 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
         float a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;
         bool running = live;
         uint32_t n_iter = 0, n_counted = 0;
+        if (DENS) {      // z_in: the depths come from the resampling instead of the uniform table.  Scratch arrays are GROUP-major,
+            // [group][sample][ray of the group]: the sixteen rays' values of one sample are 64 (sigma, depth) or 512 (geo) contiguous bytes
+            for (uint32_t i = 0; i < T; i++) {
+                const size_t at = ((size_t)grp * T + i) * 16 + c;
+                const float zs = z_in ? z_in[at] : near + span * lin[i];
+                const float x = clampf(ox + dx * zs, aabb_lo, aabb_hi), y = clampf(oy + dy * zs, aabb_lo, aabb_hi), z = clampf(oz + dz * zs, aabb_lo, aabb_hi);
+                float sigma;
+                _Float16 s16[4];
+                net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+                if (lane < 16) sigmas[at] = sigma;
+                // the sigma net's sixteen outputs (sigma's pre-activation + the 15 geometry features), 4 per quarter: what the colour
+                // net of the compositing launch needs of this sample
+                if (geo_out) {
+                    half4 h4 = {s16[0], s16[1], s16[2], s16[3]};
+                    *reinterpret_cast<half4*>(geo_out + at * 16 + (lane >> 4) * 4) = h4;
+                }
+            }
+            continue;
+        }
         float zv = near + span * lin[0];                                             // :150
         for (uint32_t i = 0; i < T; i++) {
             n_iter++;
@@ -783,6 +806,104 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
     }
 }
 
+// ray -> (group of sixteen, slot in the group) as k_render_uniform_x16 forms its groups: 1x16 strips, or 4x4-pixel blocks of frames
+// `frame_w` wide
+__device__ __forceinline__ void ray_slot(uint32_t ray, uint32_t frame_w, uint32_t& grp, uint32_t& c) {
+    if (frame_w) {
+        const uint32_t row = ray / frame_w, col = ray - row * frame_w;
+        grp = (row >> 2) * (frame_w >> 2) + (col >> 2);
+        c = (row & 3u) * 4u + (col & 3u);
+    } else {
+        grp = ray >> 4;
+        c = ray & 15u;
+    }
+}
+
+// The last launch of the large-batch importance resampling: merge + compositing ACROSS the sixteen rays of a group.  Every lane walks
+// its ray's two ascending runs -- the T uniform depths (computed) and the U resampled ones (group-major scratch) -- with two
+// pointers (coarse first on ties: the order k_merge_sorted / torch.sort of the concatenation give), so the merge costs no search and
+// no LDS; sigma and, for tiles that hold a sample with weight > 1e-4, the sigma net's outputs come from the density launches'
+// scratch, and only the colour net is evaluated here.  Transmittance is a per-lane running product, as in k_render_uniform_x16.
+template <int MODE>
+__global__ void __launch_bounds__(256, 4) k_composite_merged_x16(NetArgs na, GridLevels lv, const float* __restrict__ rays_d,
+                                                                 const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N,
+                                                                 uint32_t T, uint32_t U, const float* __restrict__ lin,
+                                                                 const float* __restrict__ sc, const float* __restrict__ zf,
+                                                                 const float* __restrict__ sf, const _Float16* __restrict__ geo_c,
+                                                                 const _Float16* __restrict__ geo_f, float* __restrict__ weights_sum,
+                                                                 float* __restrict__ depth, float* __restrict__ image,
+                                                                 float* __restrict__ aggregated_density, uint32_t dump_begin,
+                                                                 float* __restrict__ sigmas, float* __restrict__ rgbs, uint32_t frame_w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    stage_block(na, lv, Wlds, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_groups = (N + 15) / 16, Tm = T + U;
+    const float inf = __builtin_huge_valf();
+    for (uint32_t grp = wave; grp < n_groups; grp += n_waves) {
+        uint32_t ray_raw = grp * 16 + c;
+        if (frame_w) {
+            const uint32_t bpr = frame_w >> 2, by = grp / bpr, bx = grp - by * bpr;
+            ray_raw = (by * 4 + (c >> 2)) * frame_w + bx * 4 + (c & 3);
+        }
+        const bool live = ray_raw < N;
+        const uint32_t ray = live ? ray_raw : N - 1;
+        const float dx = rays_d[(size_t)ray * 3], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
+        const float near = nears[ray], far = fars[ray];
+        const float span = far - near;
+        const float sample_dist = span * (1.0f / (float)T);                          // :153
+        const bool dump = live && sigmas != nullptr && ray >= dump_begin;
+        const size_t cbase = (size_t)grp * T * 16 + c, fbase = (size_t)grp * U * 16 + c;
+        uint32_t i = 0, j = 0;                                                       // next coarse / fine sample of this lane's ray
+        float zci = near + span * lin[0], zfj = zf[fbase];
+        float carry = 1.0f, a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;
+        bool running = live;
+        for (uint32_t m = 0; m < Tm; m++) {
+            const bool from_c = zci <= zfj;                                          // (an exhausted run holds +inf; both cannot be)
+            const float zv = from_c ? zci : zfj;
+            const size_t at = from_c ? cbase + (size_t)i * 16 : fbase + (size_t)j * 16;
+            const float sigma = (from_c ? sc : sf)[at];
+            const _Float16* gp = (from_c ? geo_c : geo_f) + at * 16 + q * 4;
+            if (from_c) { i++; zci = i < T ? near + span * lin[i] : inf; }
+            else { j++; zfj = j < U ? zf[fbase + (size_t)j * 16] : inf; }
+            const float z_next = zci <= zfj ? zci : zfj;
+            const float delta = (m + 1 < Tm) ? z_next - zv : sample_dist;            // :206-207
+            const float alpha = 1.0f - expf(((-delta) * na.density_scale) * sigma);  // :208
+            const float w = alpha * carry;                                           // :210
+            const bool counted = running && lane < 16;
+            const bool masked = counted && w > 1e-4f;                                // :216
+            float cr = 0, cg = 0, cb = 0;
+            if (__ballot(masked) != 0ull) {
+                const half4 h4 = *reinterpret_cast<const half4*>(gp);
+                const _Float16 s16[4] = {h4[0], h4[1], h4[2], h4[3]};
+                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                if (!masked) { cr = 0; cg = 0; cb = 0; }
+            }
+            if (counted) {
+                a_ws += w;
+                const float qz = (zv - near) / span;                                 // :227
+                a_dep += w * (qz != qz ? qz : fminf(1.0f, fmaxf(0.0f, qz)));
+                a_r += w * cr; a_g += w * cg; a_b += w * cb;
+                a_agg += w * sigma;
+                if (dump) {
+                    const size_t row = (size_t)(ray - dump_begin) * Tm + m;
+                    sigmas[row] = sigma;
+                    rgbs[row * 3] = cr; rgbs[row * 3 + 1] = cg; rgbs[row * 3 + 2] = cb;
+                }
+                carry *= (1.0f - alpha) + 1e-15f;                                    // :209
+                if (!dump && carry < 1e-10f) running = false;
+            }
+            if (__ballot(running && lane < 16) == 0ull) break;
+        }
+        if (lane < 16 && live) {
+            weights_sum[ray] = a_ws; depth[ray] = a_dep; aggregated_density[ray] = a_agg;
+            image[(size_t)ray * 3] = a_r; image[(size_t)ray * 3 + 1] = a_g; image[(size_t)ray * 3 + 2] = a_b;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NeRFRenderer.run WITH the NeRF-style importance resampling (nerf/renderer.py:172-204, sample_pdf :12-46), evaluation mode
 // (`det`: the u of the inverse-CDF draw are the fixed linspace of :26).  One wave walks one ray; everything the reference keeps
@@ -802,7 +923,10 @@ __global__ void __launch_bounds__(256) k_render_upsample(NetArgs na, GridLevels 
                                                          uint32_t U, const float* __restrict__ lin, const float* __restrict__ u_det,
                                                          float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
                                                          float* __restrict__ aggregated_density, uint32_t dump_begin, float* __restrict__ sigmas,
-                                                         float* __restrict__ rgbs, float aabb_lo, float aabb_hi) {
+                                                         float* __restrict__ rgbs, float aabb_lo, float aabb_hi,
+                                                         const float* __restrict__ sc_in, float* __restrict__ zf_out, uint32_t frame_w) {
+    // sc_in: sigma of the uniform samples, evaluated by k_render_uniform_x16<DENS> (tiles across rays);  zf_out: stop after the resampling
+    // and hand the new depths over.  Both group-major (frame_w as in that launch): the middle launch of the large-batch form.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
@@ -825,11 +949,19 @@ __global__ void __launch_bounds__(256) k_render_upsample(NetArgs na, GridLevels 
         const float span = far - near;
         const float sample_dist = span * (1.0f / (float)T);                          // :153
         const bool dump = sigmas != nullptr && ray >= dump_begin;
+        uint32_t g_grp, g_c;
+        ray_slot(ray, frame_w, g_grp, g_c);
         // ---- 1. / 3. sigma along the ray: the T uniform depths, then (after the resampling below) the U new ones
         for (int phase = 0; phase < 2; phase++) {
             const uint32_t n = phase ? U : T;
             float* zdst = phase ? zf : zc;
             float* sdst = phase ? sf : sc;
+            if (!phase && sc_in) {  // the coarse pass was evaluated across rays: take its sigma
+                for (uint32_t i = lane; i < n; i += 64) {
+                    zdst[i] = near + span * lin[i];
+                    sdst[i] = sc_in[((size_t)g_grp * T + i) * 16 + g_c];
+                }
+            } else
             for (uint32_t i0 = 0; i0 < n; i0 += 16) {
                 const uint32_t idx = i0 + c;
                 const bool valid = idx < n;
@@ -899,9 +1031,12 @@ __global__ void __launch_bounds__(256) k_render_upsample(NetArgs na, GridLevels 
                 const float b0 = zc[below] + 0.5f * (zc[below + 1] - zc[below]);     // :174 mid points
                 const float b1 = zc[above] + 0.5f * (zc[above + 1] - zc[above]);
                 zf[sI] = b0 + tq * (b1 - b0);                                        // :44
+                if (zf_out) zf_out[((size_t)g_grp * U + sI) * 16 + g_c] = zf[sI];
             }
             NGP_WAVE_SYNC();
+            if (zf_out) break;
         }
+        if (zf_out) { NGP_WAVE_SYNC(); continue; }
         // ---- 4. merge: rank of every element in the other run (coarse first on ties)
         for (uint32_t k = lane; k < Tm; k += 64) {
             float v, sg;
@@ -2607,13 +2742,13 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
         if (gb > 1024) gb = 1024;
         if (needs_generic(lv))
             k_render_uniform_x16<1><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps, nullptr, nullptr);
         else if (na.cells)
             k_render_uniform_x16<2><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps, nullptr, nullptr);
         else
             k_render_uniform_x16<0><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps);
+                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps, nullptr, nullptr);
         return check_launch("render_uniform");
     }
     if (needs_generic(lv))
@@ -2628,9 +2763,19 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     return check_launch("render_uniform");
 }
 
+// sigma of the coarse pass [N, T], depths and sigma of the fine pass [N, U] x 2 (fp32), the sigma net's outputs of both [N, T + U, 16] (fp16)
+static size_t upsample_workspace_bytes(uint32_t N, uint32_t T, uint32_t U) {
+    const size_t Np = ((size_t)N + 15) / 16 * 16;          // whole groups of sixteen rays
+    return Np * (((size_t)T + 2 * (size_t)U) * sizeof(float) + ((size_t)T + U) * 16 * sizeof(_Float16));
+}
+size_t ngp_render_upsample_workspace(uint32_t N, uint32_t T, uint32_t U) {
+    return N >= kUniformX16MinRays ? upsample_workspace_bytes(N, T, U) : 0;
+}
+
 int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N,
                         uint32_t T, uint32_t U, const float* lin, const float* u, float* weights_sum, float* depth, float* image,
-                        float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs, ngp_stream_t stream) {
+                        float* aggregated_density, uint32_t dump_begin, float* sigmas, float* rgbs, uint32_t frame_width, void* workspace,
+                        size_t workspace_bytes, ngp_stream_t stream) {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && nears && fars && lin && u && weights_sum && depth && image && aggregated_density, "render_upsample: null pointer");
     NGP_REQUIRE((sigmas == nullptr) == (rgbs == nullptr), "render_upsample: sigmas and rgbs must both be given or both NULL");
@@ -2654,15 +2799,65 @@ int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float
     uint32_t blocks = div_up(N, waves);
     if (blocks > 1024) blocks = 1024;
     ProfScope prof("render_upsample", s, (double)N * (T + U));
-    if (needs_generic(lv))
-        k_render_upsample<1><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
-                                                             aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
-    else if (na.cells)
-        k_render_upsample<2><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
-                                                             aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    const int mode = needs_generic(lv) ? 1 : (na.cells ? 2 : 0);
+    uint32_t fw = frame_width;
+    if (fw && (fw % 4 != 0 || N % (4 * fw) != 0)) fw = 0;
+    auto per_ray = [&](const float* sc_in, float* zf_out) {
+        if (mode == 1)
+            k_render_upsample<1><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
+                                                                 aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound, sc_in, zf_out, fw);
+        else if (mode == 2)
+            k_render_upsample<2><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
+                                                                 aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound, sc_in, zf_out, fw);
+        else
+            k_render_upsample<0><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
+                                                                 aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound, sc_in, zf_out, fw);
+    };
+    const size_t need = upsample_workspace_bytes(N, T, U);
+    if (!(workspace && workspace_bytes >= need && N >= kUniformX16MinRays && getenv("NGP_UPSAMPLE_PER_RAY") == nullptr)) {
+        per_ray(nullptr, nullptr);      // everything along the ray in one launch
+        return check_launch("render_upsample");
+    }
+    // Large batches: four launches through the caller's scratch (group-major arrays, see k_render_uniform_x16<DENS>).  The two density
+    // passes take their tiles ACROSS sixteen neighbouring rays (twice the per-sample rate of tiles along a ray) and keep the sigma
+    // net's outputs; the per-ray kernel resamples between them; merge + compositing run across the rays as well, colour net only.
+    const size_t Np = ((size_t)N + 15) / 16 * 16;
+    float* sc = reinterpret_cast<float*>(workspace);
+    float* zf = sc + Np * T;
+    float* sf = zf + Np * U;
+    _Float16* gc = reinterpret_cast<_Float16*>(sf + Np * U);
+    _Float16* gf = gc + Np * T * 16;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<0, true>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<1, true>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<2, true>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_composite_merged_x16<0>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_composite_merged_x16<1>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_composite_merged_x16<2>), 96 * 1024);
+    uint32_t gb = div_up(div_up(N, 16), 4);
+    if (gb > 1024) gb = 1024;
+    auto density = [&](uint32_t n, const float* z_in, float* out, _Float16* geo) {
+        if (mode == 1)
+            k_render_uniform_x16<1, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
+                                                                 nullptr, -model->bound, model->bound, fw, nullptr, z_in, geo);
+        else if (mode == 2)
+            k_render_uniform_x16<2, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
+                                                                 nullptr, -model->bound, model->bound, fw, nullptr, z_in, geo);
+        else
+            k_render_uniform_x16<0, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
+                                                                 nullptr, -model->bound, model->bound, fw, nullptr, z_in, geo);
+    };
+    density(T, nullptr, sc, gc);
+    per_ray(sc, zf);
+    density(U, zf, sf, gf);
+    if (mode == 1)
+        k_composite_merged_x16<1><<<gb, 256, fixed, s>>>(na, lv, rays_d, nears, fars, N, T, U, lin, sc, zf, sf, gc, gf, weights_sum, depth, image,
+                                                         aggregated_density, dump_begin, sigmas, rgbs, fw);
+    else if (mode == 2)
+        k_composite_merged_x16<2><<<gb, 256, fixed, s>>>(na, lv, rays_d, nears, fars, N, T, U, lin, sc, zf, sf, gc, gf, weights_sum, depth, image,
+                                                         aggregated_density, dump_begin, sigmas, rgbs, fw);
     else
-        k_render_upsample<0><<<blocks, 64 * waves, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, U, lin, u, weights_sum, depth, image,
-                                                             aggregated_density, dump_begin, sigmas, rgbs, -model->bound, model->bound);
+        k_composite_merged_x16<0><<<gb, 256, fixed, s>>>(na, lv, rays_d, nears, fars, N, T, U, lin, sc, zf, sf, gc, gf, weights_sum, depth, image,
+                                                         aggregated_density, dump_begin, sigmas, rgbs, fw);
     return check_launch("render_upsample");
 }
 

@@ -350,7 +350,8 @@ class NeRFRenderer(nn.Module):
                 nears, fars = raymarching.near_far_from_aabb(o, d, aabb, self.min_near)
             last_begin = ((N - 1) // max_ray_batch) * max_ray_batch          # first ray of the chunk the reference loop ends with
             if upsample_steps > 0:      # importance resampling (evaluation mode, no gradients: the caller checked)
-                ws, dep, img, ag, sigmas, rgbs = fm.render_upsample(o, d, nears, fars, int(num_steps), int(upsample_steps), last_begin)
+                ws, dep, img, ag, sigmas, rgbs = fm.render_upsample(o, d, nears, fars, int(num_steps), int(upsample_steps), last_begin,
+                                                                    int(kwargs.get("frame_width", 0) or 0))
             else:
                 ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin, int(kwargs.get("frame_width", 0) or 0))
             img = img + (1 - ws).unsqueeze(-1) * (1 if bg_color is None else bg_color)

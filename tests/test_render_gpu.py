@@ -349,6 +349,42 @@ def test_run_full_size_frame_properties(setup, device, monkeypatch):
     assert err.max() < 2.5e-4 and err.mean() < 1e-5          # 2 x the observed 1.0e-4 / 4.5e-6
 
 
+@pytest.mark.parametrize("backbone,T,U,fw", [("ff", 64, 48, 0), ("linear", 40, 72, 260)])
+def test_resampling_with_density_passes_across_rays(setup, device, backbone, T, U, fw, monkeypatch):
+    """ngp_render_upsample from 65 536 rays on: the coarse and the fine density pass take their tiles across sixteen neighbouring rays
+    (k_render_uniform_x16<DENS>), the per-ray kernel resamples between them, merge + compositing run across the rays too
+    (k_composite_merged_x16: two-pointer merge per lane, colour net on the kept sigma-net outputs) -- four launches through a caller
+    workspace.  Same samples as the one-launch form (NGP_UPSAMPLE_PER_RAY), with or without the frame-width hint; rays that miss the
+    box and a dumped last chunk included."""
+    from nerfsafetyvalidation_amd import raymarching
+    sc = _scene(H=256, W=260)
+    model = sc.build_model(device, backbone=backbone, cuda_ray=False)
+    ro, rd = Hh.pinhole_rays(sc.poses[47], sc.intrinsics, sc.H, sc.W)
+    rd[1000:1040] = -rd[1000:1040]
+    o, d = _t(ro, device), _t(rd, device)
+    N = o.shape[0]
+    assert N >= 65536
+    res = {}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        fm = model.fused_model()
+        nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_infer, model.min_near)
+        for form in ("across", "along"):
+            if form == "along":
+                monkeypatch.setenv("NGP_UPSAMPLE_PER_RAY", "1")
+            res[form] = fm.render_upsample(o, d, nears, fars, T, U, N - 2500, fw)
+    monkeypatch.delenv("NGP_UPSAMPLE_PER_RAY")
+    # the samples (their sigmas and colours, dumped for the last 2500 rays) are the same bits; the per-ray sums run over them in a
+    # different order (running product per lane / scan per tile): fp32 summation order
+    for i, (a, b) in enumerate(zip(res["across"], res["along"])):
+        assert a.shape == b.shape and torch.equal(torch.isnan(a), torch.isnan(b))
+        a, b = torch.nan_to_num(a), torch.nan_to_num(b)
+        if i >= 4:
+            assert torch.equal(a, b), i
+        else:
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), i
+    assert res["across"][4].shape[0] == 2500 * (T + U)
+
+
 @pytest.mark.parametrize("backbone", ["ff", "linear"])
 def test_run_kernel_forms_agree(setup, device, backbone):
     """ngp_render_uniform takes its tiles across sixteen neighbouring rays from 65 536 rays on (k_render_uniform_x16) and along one ray
