@@ -385,6 +385,25 @@ def test_resampling_with_density_passes_across_rays(setup, device, backbone, T, 
     assert res["across"][4].shape[0] == 2500 * (T + U)
 
 
+@pytest.mark.parametrize("U", [0, 32])
+def test_run_path_several_cameras_per_call(setup, device, U):
+    """render(staged=True) through `run` with rays [B, N, 3]: every camera's frame equals its own single-camera call (the frame-width
+    hint applies per camera; the per-sample tensors are those of the LAST camera's last chunk, as the reference's loop leaves them)."""
+    sc = _scene(H=64, W=64)
+    model = sc.build_model(device, cuda_ray=False)
+    rays = [Hh.pinhole_rays(sc.poses[v], sc.intrinsics, sc.H, sc.W) for v in (5, 90, 171)]
+    o = torch.stack([_t(r[0], device) for r in rays]); d = torch.stack([_t(r[1], device) for r in rays])
+    kw = dict(staged=True, max_ray_batch=1000, bg_color=1, perturb=False, num_steps=64, upsample_steps=U, frame_width=64)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        both = model.render(o, d, **kw)
+        singles = [model.render(o[i:i + 1], d[i:i + 1], **kw) for i in range(3)]
+    for k in ("image", "depth", "aggregated_density"):
+        assert both[k].shape[0] == 3
+        for i in range(3):
+            assert torch.equal(both[k][i], singles[i][k][0]), (k, i)
+    assert torch.equal(both["rgbs"], singles[2]["rgbs"]) and torch.equal(both["sigmas"], singles[2]["sigmas"])
+
+
 @pytest.mark.parametrize("backbone", ["ff", "linear"])
 def test_run_kernel_forms_agree(setup, device, backbone):
     """ngp_render_uniform takes its tiles across sixteen neighbouring rays from 65 536 rays on (k_render_uniform_x16) and along one ray
