@@ -73,6 +73,7 @@ class FusedModel:
         self._tls = threading.local()
         # per-cell corner records (ngp_build_cell_tables): built on first use within this budget (GB); 0 disables them
         self.cell_table_gb = float(os.environ.get("NGP_CELL_TABLE_GB", getattr(net, "fused_cell_table_gb", 48)))
+        self._lin_cache = {}
         self._cells = None
         self._cell_levels = 0
         self._cells_ready = False
@@ -250,7 +251,7 @@ class FusedModel:
         frame_width: the rays are the pixels of row-major frames this wide (scheduling hint, results do not depend on it)"""
         self._ensure_cells()
         N, T, dev = rays_o.shape[0], int(num_steps), rays_o.device
-        lin = torch.linspace(0.0, 1.0, T, device=dev)
+        lin = self._linspace(0.0, 1.0, T)
         out = [torch.empty(N, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
                torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)]
         n_dump = N - dump_begin
@@ -263,6 +264,17 @@ class FusedModel:
                                           dump_begin, _lib.ptr(sigmas), _lib.ptr(rgbs), int(frame_width or 0), _lib.stream()), "render_uniform")
         return out[0], out[1], out[2], out[3], sigmas, rgbs
 
+    def _linspace(self, lo, hi, n):
+        """torch.linspace(lo, hi, n) on the model's device, made once per (lo, hi, n): the state estimator calls the fused run a
+        hundred times per simulator step with the same table (read-only in every kernel)"""
+        key = (float(lo), float(hi), int(n))
+        t = self._lin_cache.get(key)
+        if t is None:
+            t = torch.linspace(lo, hi, n, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()      # other streams may read it next (frames in flight)
+            self._lin_cache[key] = t
+        return t
+
     def upsample_fits(self, num_steps, upsample_steps):
         """LDS budget of ngp_render_upsample: the packed weights + (5 T + 4 U) floats for at least one ray"""
         weights = 2 * ((2048 + self.sigma_mm * 4096 + 1024) + (2048 + self.color_mm * 4096 + 1024))
@@ -274,8 +286,8 @@ class FusedModel:
         (scratch from torch's allocator; frame_width: scheduling hint) -- the same bits either way"""
         self._ensure_cells()
         N, T, U, dev = rays_o.shape[0], int(num_steps), int(upsample_steps), rays_o.device
-        lin = torch.linspace(0.0, 1.0, T, device=dev)
-        u = torch.linspace(0.0 + 0.5 / U, 1.0 - 0.5 / U, steps=U, device=dev)        # renderer.py:26
+        lin = self._linspace(0.0, 1.0, T)
+        u = self._linspace(0.0 + 0.5 / U, 1.0 - 0.5 / U, U)                            # renderer.py:26
         out = [torch.empty(N, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
                torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)]
         n_dump = N - dump_begin
@@ -304,7 +316,7 @@ class FusedModel:
                     torch.cuda.current_stream(self.device).synchronize()
                     self._packed_bwd = buf
         N, T, dev = rays_o.shape[0], int(num_steps), rays_o.device
-        lin = torch.linspace(0.0, 1.0, T, device=dev)
+        lin = self._linspace(0.0, 1.0, T)
         f32 = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
         go = torch.empty(N, 3, dtype=torch.float32, device=dev)
         gd = torch.empty(N, 3, dtype=torch.float32, device=dev)
