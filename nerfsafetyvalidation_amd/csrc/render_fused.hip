@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
             // [group][sample][ray of the group]: the sixteen rays' values of one sample are 64 (sigma, depth) or 512 (geo) contiguous bytes
             for (uint32_t i = 0; i < T; i++) {
                 const size_t at = ((size_t)grp * T + i) * 16 + c;
-                const float zs = z_in ? z_in[at] : near + span * lin[i];
+                const float zs = z_in ? (live ? z_in[at] : 0.0f) : near + span * lin[i];    // (slots past the last ray were never written)
                 const float x = clampf(ox + dx * zs, aabb_lo, aabb_hi), y = clampf(oy + dy * zs, aabb_lo, aabb_hi), z = clampf(oz + dz * zs, aabb_lo, aabb_hi);
                 float sigma;
                 _Float16 s16[4];
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(256, 4) k_composite_merged_x16(NetArgs na, Gri
         const bool dump = live && sigmas != nullptr && ray >= dump_begin;
         const size_t cbase = (size_t)grp * T * 16 + c, fbase = (size_t)grp * U * 16 + c;
         uint32_t i = 0, j = 0;                                                       // next coarse / fine sample of this lane's ray
-        float zci = near + span * lin[0], zfj = zf[fbase];
+        float zci = near + span * lin[0], zfj = live ? zf[fbase] : 0.0f;                 // (slots past the last ray were never written)
         float carry = 1.0f, a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;
         bool running = live;
         for (uint32_t m = 0; m < Tm; m++) {
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(256, 4) k_composite_merged_x16(NetArgs na, Gri
             const float sigma = (from_c ? sc : sf)[at];
             const _Float16* gp = (from_c ? geo_c : geo_f) + at * 16 + q * 4;
             if (from_c) { i++; zci = i < T ? near + span * lin[i] : inf; }
-            else { j++; zfj = j < U ? zf[fbase + (size_t)j * 16] : inf; }
+            else { j++; zfj = j < U ? (live ? zf[fbase + (size_t)j * 16] : 0.0f) : inf; }
             const float z_next = zci <= zfj ? zci : zfj;
             const float delta = (m + 1 < Tm) ? z_next - zv : sample_dist;            // :206-207
             const float alpha = 1.0f - expf(((-delta) * na.density_scale) * sigma);  // :208
