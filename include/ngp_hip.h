@@ -224,7 +224,14 @@ typedef struct ngp_model {
     const void* packed_weights;   /* the two blobs as MFMA fragments (ngp_pack_weights; ngp_packed_weights_bytes() bytes of device
                                      memory, 16-byte aligned), packed once per parameter version.  Required by
                                      ngp_network_forward / ngp_render_uniform; ngp_render_rays packs into its context when NULL */
+    uint32_t precision;           /* NGP_PREC_F16 (0): fp16 table and weight blobs, as described above.  NGP_PREC_F32: `embeddings` is the
+                                     fp32 table [sO,2] and the two blobs are fp32 in the same layout -- the arithmetic of the reference's
+                                     rollout, which renders outside any autocast context (validate.py:288-291; gridencoder/grid.py:36-39
+                                     and nn.Linear then stay fp32).  Served by ngp_pack_weights(_bwd), ngp_network_forward / _density
+                                     (+ _backward) and ngp_render_uniform (+ _backward); the other fused entry points take fp16 */
 } ngp_model;
+#define NGP_PREC_F16 0u
+#define NGP_PREC_F32 1u
 
 /* fragment-major copy of model->sigma_weights / color_weights for the fused kernels (layout: render_fused.hip, k_pack_weights) */
 NGP_API size_t ngp_packed_weights_bytes(void);
@@ -284,10 +291,17 @@ NGP_API int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const f
 NGP_API int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas,
                         float* rgbs, ngp_stream_t stream);
 
-/* the density half alone (NeRFNetwork.density, nerf/network_ff.py:77-90): sigmas [M] f32, raw trunc_exp output */
-NGP_API int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, float* sigmas, ngp_stream_t stream);
+/* the density half alone (NeRFNetwork.density, nerf/network.py:126-143, nerf/network_ff.py:77-90): sigmas [M] f32, raw trunc_exp
+ * output; geo_feat (may be NULL) [M,15] f32, the sigma net's outputs 1..15 the reference returns next to sigma */
+NGP_API int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, ngp_stream_t stream);
+/* Its vector-Jacobian product with respect to the POINTS, map frozen: what the trajectory planner differentiates
+ * (nav/quad_plot.py:223-249 through validate.py:288's density_fn: ~6 k body points, 250 Adam steps per simulator step).
+ * grad_sigmas [M] and grad_geo_feat [M,15] (either may be NULL = zero) -> grad_xyzs [M,3] (overwritten).  One launch, nothing saved
+ * by the forward call; packed_weights_bwd as for ngp_render_uniform_backward. */
+NGP_API int ngp_network_density_backward(const ngp_model* model, const void* packed_weights_bwd, const float* xyzs, uint32_t M,
+                                 const float* grad_sigmas, const float* grad_geo_feat, float* grad_xyzs, ngp_stream_t stream);
 
-/* NeRFRenderer.run (nerf/renderer.py:125-258) for upsample_steps == 0 and perturb == False with the fp16 network: T uniform
+/* NeRFRenderer.run (nerf/renderer.py:125-258) for upsample_steps == 0 and perturb == False (fp16 or fp32 network, ngp_model::precision): T uniform
  * samples per ray between nears and fars (lin = the T values of torch.linspace(0, 1, T), device memory), hash grid + sigma net
  * on every sample, transmittance scan, colour net where weight > 1e-4, and the per-ray sums.  Outputs: weights_sum [N],
  * depth [N] (sum of weights * clamp((z - near) / (far - near), 0, 1)), image [N,3] (BEFORE the background mix),
@@ -325,6 +339,9 @@ NGP_API size_t ngp_render_upsample_workspace(uint32_t N, uint32_t T, uint32_t U)
  * (160 KB: both weight sets + 12 B per sample and resident wave) must hold, else NGP_EINVAL: T <= 512 for the reference's networks. */
 NGP_API size_t ngp_packed_weights_bwd_bytes(void);
 NGP_API int ngp_pack_weights_bwd(const ngp_model* model, void* out, ngp_stream_t stream);
+/* bytes of LDS ngp_render_uniform_backward needs for this model and T samples per ray ((size_t)-1: a shape it does not serve);
+ * the call fits when this is <= 160 KB */
+NGP_API size_t ngp_render_uniform_backward_lds(const ngp_model* model, uint32_t T);
 NGP_API int ngp_render_uniform_backward(const ngp_model* model, const void* packed_weights_bwd, const float* rays_o, const float* rays_d,
                                 const float* nears, const float* fars, uint32_t N, uint32_t T, const float* lin, const float* grad_image,
                                 const float* grad_depth, const float* grad_weights_sum, const float* grad_aggregated_density,
@@ -418,6 +435,7 @@ NGP_API int ngp_debug_disable_march_queue(int off);
  * accumulation of the 8 corners, one rounding); 1: the grid_encode operator's (c10::Half product and running sum,
  * gridencoder.cu:169-172) through the same gather -- bit-identical to ngp_grid_encode_forward, which is how the default's
  * deviation from the reference arithmetic is measured (tests/test_render_gpu.py). */
+/* With an NGP_PREC_F32 model `features` is float [M,32] and operator_rounding is ignored (one arithmetic: the operator's fmaf chain). */
 NGP_API int ngp_debug_fused_features(const ngp_model* model, const float* xyzs, uint32_t M, int operator_rounding, uint16_t* features,
                              ngp_stream_t stream);
 /* Diagnostics of ngp_render_uniform_backward: float [N][T][4] device buffer receiving, per sample, sigma, the transmittance before

@@ -1,11 +1,14 @@
 """Host glue for the fused MI355X render entry points (ngp_render_rays / ngp_network_forward).
 
-A FusedModel snapshots what the C ABI's `ngp_model` needs from a NeRFNetwork: the fp16 hash table,
-the two fp16 weight blobs in FFMLP layout, the occupancy bitfield and the scalar hyper-parameters.
+A FusedModel snapshots what the C ABI's `ngp_model` needs from a NeRFNetwork: the hash table,
+the two weight blobs in FFMLP layout, the occupancy bitfield and the scalar hyper-parameters.
 Parameters are re-snapshotted when their torch version counters change, so the object can be cached
 on the module.  The nn.Linear backbone (nerf/network.py) is zero-padded to the fused shapes:
     sigma : W1 [64,32], W2 [16,64]                        -> blob [64x32 | 16x64]          (0 hidden matmuls)
     colour: W1 [64,31], W2 [64,64], W3 [3,64]             -> blob [64x32 | 64x64 | 16x64]  (1 hidden matmul)
+Two precisions (ngp_model::precision): fp16 table + fp16 blobs -- what the reference evaluates under autocast -- and, for the
+nn.Linear backbone OUTSIDE autocast, the fp32 table itself + fp32 blobs: validate.py's rollout calls model.render / model.density
+with no autocast context (validate.py:288-291), so gridencoder/grid.py:36-39 keeps the table fp32 and nn.Linear runs fp32 GEMMs.
 """
 import ctypes as C
 import os
@@ -45,17 +48,47 @@ def _versions(tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors)
 
 
+class NetworkDensity(torch.autograd.Function):
+    """NeRFNetwork.density (nerf/network.py:126-143) as ONE launch forward (ngp_network_density) and ONE backward
+    (ngp_network_density_backward) -- differentiable in the points, the map frozen: the trajectory planner's
+    d sigma / d x (nav/quad_plot.py:223-249 through validate.py:288's density_fn)."""
+
+    @staticmethod
+    def forward(ctx, fm, x):
+        x = x.float().contiguous()
+        sigma, geo = fm.network_density(x, want_geo=True)
+        ctx.fm = fm
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)       # an unused output (the planner never touches geo_feat) arrives as None, not as zeros
+        return sigma, geo
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_geo):
+        (x,) = ctx.saved_tensors
+        if g_sigma is None and g_geo is None:
+            return None, torch.zeros_like(x)
+        return None, ctx.fm.network_density_backward(x, g_sigma, g_geo)
+
+
 class FusedModel:
-    def __init__(self, net, sigma_blob, sigma_mm, color_blob, color_mm, watched):
+    def __init__(self, net, sigma_blob, sigma_mm, color_blob, color_mm, watched, f32=False):
         from .gridencoder.grid import derived_tables
         enc = net.encoder
         if enc.input_dim != 3 or enc.num_levels != 16 or enc.level_dim != 2:
             raise RuntimeError("fused renderer needs the 3-D, 16-level, 2-feature hash grid")
-        # fp16 copy of the table and, later, its per-cell records: shared with the grid_encode operator (one entry per parameter version)
-        self._tables = derived_tables(enc.embeddings)
-        emb16 = self._tables.emb16
+        self.f32 = bool(f32)
+        if self.f32:
+            # the reference reads the fp32 parameter itself outside autocast (gridencoder/grid.py:36-39): no copy, no per-cell records
+            if enc.embeddings.dtype != torch.float32:
+                raise RuntimeError("fp32 fused model needs an fp32 table")
+            self._tables = None
+            emb16 = enc.embeddings.detach().contiguous()
+        else:
+            # fp16 copy of the table and, later, its per-cell records: shared with the grid_encode operator (one entry per parameter version)
+            self._tables = derived_tables(enc.embeddings)
+            emb16 = self._tables.emb16
         self.device = emb16.device
-        self.emb16, self.sigma_blob, self.color_blob = emb16, sigma_blob, color_blob
+        self.emb16, self.sigma_blob, self.color_blob = emb16, sigma_blob, color_blob      # (emb16: the table in the model's precision)
         self.sigma_mm, self.color_mm = sigma_mm, color_mm
         self.offsets_host = _lib.host_i32(enc.offsets)
         self.S = float(np.log2(enc.per_level_scale))
@@ -91,16 +124,18 @@ class FusedModel:
                    net.color_net.weights.detach().half().contiguous(), net.num_layers_color - 1, watched)
 
     @classmethod
-    def from_linear_network(cls, net):
+    def from_linear_network(cls, net, f32=False):
+        dtype = torch.float32 if f32 else torch.half
+
         def blob(layers, in_pad):
             parts = []
             for i, layer in enumerate(layers):
-                w = layer.weight.detach().half()
+                w = layer.weight.detach().to(dtype)
                 rows = 16 if i == len(layers) - 1 else 64
                 cols = in_pad if i == 0 else 64
                 if w.shape[0] > rows or w.shape[1] > cols or (0 < i < len(layers) - 1 and tuple(w.shape) != (64, 64)):
                     raise RuntimeError(f"layer {i} of shape {tuple(w.shape)} does not fit the fused {rows}x{cols} slot")
-                full = torch.zeros(rows, cols, dtype=torch.half, device=w.device)
+                full = torch.zeros(rows, cols, dtype=dtype, device=w.device)
                 full[:w.shape[0], :w.shape[1]] = w
                 parts.append(full.reshape(-1))
             return torch.cat(parts).contiguous()
@@ -108,7 +143,9 @@ class FusedModel:
         if net.hidden_dim != 64 or net.hidden_dim_color != 64 or net.geo_feat_dim != 15:
             raise RuntimeError("fused renderer needs 64-wide MLPs and geo_feat_dim == 15")
         watched = [net.encoder.embeddings] + [l.weight for l in net.sigma_net] + [l.weight for l in net.color_net]
-        return cls(net, blob(net.sigma_net, 32), len(net.sigma_net) - 2, blob(net.color_net, 32), len(net.color_net) - 2, watched)
+        if f32 and (len(net.sigma_net) - 2 > 1 or len(net.color_net) - 2 > 2):
+            raise RuntimeError("fp32 fused model: at most 3 sigma and 4 colour layers (the backward kernels keep that many activations)")
+        return cls(net, blob(net.sigma_net, 32), len(net.sigma_net) - 2, blob(net.color_net, 32), len(net.color_net) - 2, watched, f32=f32)
 
     def valid_for(self, net):
         return (_versions(self._watched) == self._snapshot and self.density_scale == float(net.density_scale)
@@ -128,6 +165,7 @@ class FusedModel:
         m.cell_tables = _lib.ptr(self._cells) if self._cells is not None else None
         m.cell_levels = self._cell_levels
         m.packed_weights = _lib.ptr(self._packed) if self._packed is not None else None
+        m.precision = _lib.NGP_PREC_F32 if self.f32 else _lib.NGP_PREC_F16
         return m
 
     def _ensure_packed(self):
@@ -149,7 +187,7 @@ class FusedModel:
         self._ensure_packed()
         if self._cells_ready:
             return
-        if self.cell_table_gb > 0:
+        if self.cell_table_gb > 0 and not self.f32:
             self._cells, self._cell_levels = self._tables.ensure_cells(self.offsets_host, self.S, self.H_base, self.gridtype, self.align_corners,
                                                                        self.cell_table_gb)
         self._cells_ready = True
@@ -167,16 +205,43 @@ class FusedModel:
                    "network_forward")
         return sigmas, rgbs
 
-    def network_density(self, xyzs):
-        """fused NeRFNetwork.density: xyzs [M,3] f32 -> sigma [M] f32 (unscaled).  Does not build the per-cell records (it serves the
-        density-grid maintenance during training, where the snapshot is rebuilt whenever the parameters move)."""
+    def network_density(self, xyzs, want_geo=False):
+        """fused NeRFNetwork.density: xyzs [M,3] f32 -> sigma [M] f32 (unscaled) (, geo_feat [M,15] f32).  Does not build the per-cell
+        records (it serves the density-grid maintenance during training, where the snapshot is rebuilt whenever the parameters move)."""
         xyzs = xyzs.float().contiguous()
         self._ensure_packed()
         M = xyzs.shape[0]
         sigmas = torch.empty(M, dtype=torch.float32, device=xyzs.device)
+        geo = torch.empty(M, 15, dtype=torch.float32, device=xyzs.device) if want_geo else None
         m = self._struct(None)
-        _lib.check(_lib.lib().ngp_network_density(C.byref(m), _lib.ptr(xyzs), M, _lib.ptr(sigmas), _lib.stream()), "network_density")
-        return sigmas
+        _lib.check(_lib.lib().ngp_network_density(C.byref(m), _lib.ptr(xyzs), M, _lib.ptr(sigmas), _lib.ptr(geo), _lib.stream()), "network_density")
+        return (sigmas, geo) if want_geo else sigmas
+
+    def _ensure_packed_bwd(self):
+        """the transposed weights as MFMA fragments (ngp_pack_weights_bwd), once per snapshot"""
+        if self._packed_bwd is None:
+            lib = _lib.lib()
+            with self._ctx_lock:
+                if self._packed_bwd is None:
+                    buf = torch.empty(lib.ngp_packed_weights_bwd_bytes(), dtype=torch.uint8, device=self.device)
+                    _lib.check(lib.ngp_pack_weights_bwd(C.byref(self._struct(None)), _lib.ptr(buf), _lib.stream()), "pack_weights_bwd")
+                    torch.cuda.current_stream(self.device).synchronize()
+                    self._packed_bwd = buf
+        return self._packed_bwd
+
+    def network_density_backward(self, xyzs, g_sigma=None, g_geo=None):
+        """vector-Jacobian product of network_density w.r.t. the points, map frozen (ngp_network_density_backward):
+        g_sigma [M], g_geo [M,15] (None = zero) -> grad_xyzs [M,3]"""
+        self._ensure_packed()
+        packed_bwd = self._ensure_packed_bwd()
+        xyzs = xyzs.float().contiguous()
+        M = xyzs.shape[0]
+        f32 = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
+        gx = torch.empty(M, 3, dtype=torch.float32, device=xyzs.device)
+        m = self._struct(None)
+        _lib.check(_lib.lib().ngp_network_density_backward(C.byref(m), _lib.ptr(packed_bwd), _lib.ptr(xyzs), M, _lib.ptr(f32(g_sigma)),
+                                                           _lib.ptr(f32(g_geo)), _lib.ptr(gx), _lib.stream()), "network_density_backward")
+        return gx
 
     def _pad_value(self):
         """what the network returns for the reference's zero-filled padding rows (xyz = 0, dir = 0)"""
@@ -277,6 +342,8 @@ class FusedModel:
 
     def upsample_fits(self, num_steps, upsample_steps):
         """LDS budget of ngp_render_upsample: the packed weights + (5 T + 4 U) floats for at least one ray"""
+        if self.f32:
+            return False            # (the resampling kernels exist for the fp16 network only; fp32 takes the operators)
         weights = 2 * ((2048 + self.sigma_mm * 4096 + 1024) + (2048 + self.color_mm * 4096 + 1024))
         return num_steps >= 3 and upsample_steps >= 1 and weights + 2048 + 4 * (5 * num_steps + 4 * upsample_steps) <= 159 * 1024
 
@@ -308,13 +375,7 @@ class FusedModel:
         image (before the background mix) [N,3], depth / weights_sum / aggregated_density [N] (None = zero) -> grad_rays_o, grad_rays_d"""
         self._ensure_cells()
         lib = _lib.lib()
-        if self._packed_bwd is None:
-            with self._ctx_lock:
-                if self._packed_bwd is None:
-                    buf = torch.empty(lib.ngp_packed_weights_bwd_bytes(), dtype=torch.uint8, device=self.device)
-                    _lib.check(lib.ngp_pack_weights_bwd(C.byref(self._struct(None)), _lib.ptr(buf), _lib.stream()), "pack_weights_bwd")
-                    torch.cuda.current_stream(self.device).synchronize()
-                    self._packed_bwd = buf
+        self._ensure_packed_bwd()
         N, T, dev = rays_o.shape[0], int(num_steps), rays_o.device
         lin = self._linspace(0.0, 1.0, T)
         f32 = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
@@ -328,10 +389,9 @@ class FusedModel:
         return go, gd
 
     def uniform_backward_fits(self, num_steps):
-        """LDS budget of the fused backward (160 KB): both weight sets + 12 bytes per sample for each of its 8 resident rays"""
-        weights = 2 * ((2048 + self.sigma_mm * 4096 + 1024) + (2048 + self.color_mm * 4096 + 1024))
-        weights += 2 * ((4096 + self.sigma_mm * 4096) + (4096 + self.color_mm * 4096))
-        return num_steps <= 1024 and weights + 1024 + 8 * 12 * num_steps <= 160 * 1024
+        """LDS budget of the fused backward (160 KB): both weight sets + 12 bytes per sample for each of its resident rays"""
+        need = _lib.lib().ngp_render_uniform_backward_lds(C.byref(self._struct(None)), int(num_steps))
+        return num_steps <= 1024 and need <= 160 * 1024
 
     def __del__(self):
         try:

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("NGP_HIP_LIB", os.path.join(_HERE, "libngp_hip.so"))   # (the override: A/B builds of experiments, scripts/build_variant.sh)
 
 NGP_F32, NGP_F16 = 0, 1
+NGP_PREC_F16, NGP_PREC_F32 = 0, 1          # ngp_model::precision
 
 _vp, _u32, _f32, _int, _sz = C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_size_t
 
@@ -27,6 +28,7 @@ class ModelStruct(C.Structure):
         ("align_corners", _int), ("sigma_weights", _vp), ("sigma_hidden_mm", _u32), ("color_weights", _vp),
         ("color_hidden_mm", _u32), ("bound", _f32), ("density_scale", _f32), ("density_bitfield", _vp),
         ("cascade", _u32), ("grid_size", _u32), ("cell_tables", _vp), ("cell_levels", _u32), ("packed_weights", _vp),
+        ("precision", _u32),
     ]
 
 
@@ -83,7 +85,9 @@ SIGNATURES = {
     "ngp_render_rays": [_vp, C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                         C.POINTER(C.c_float), C.POINTER(RenderStats), _int, _vp],
     "ngp_network_forward": [C.POINTER(ModelStruct), _vp, _vp, _u32, _vp, _vp, _vp],
-    "ngp_network_density": [C.POINTER(ModelStruct), _vp, _u32, _vp, _vp],
+    "ngp_network_density": [C.POINTER(ModelStruct), _vp, _u32, _vp, _vp, _vp],
+    "ngp_network_density_backward": [C.POINTER(ModelStruct), _vp, _vp, _u32, _vp, _vp, _vp, _vp],
+    "ngp_render_uniform_backward_lds": [C.POINTER(ModelStruct), _u32],
     "ngp_packed_weights_bwd_bytes": [],
     "ngp_pack_weights_bwd": [C.POINTER(ModelStruct), _vp, _vp],
     "ngp_render_uniform_backward": [C.POINTER(ModelStruct), _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -111,7 +115,7 @@ SIGNATURES = {
     "ngp_prof_reset": [],
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
-_RESTYPES = {"ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_packed_weights_bwd_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
+_RESTYPES = {"ngp_render_uniform_backward_lds": _sz, "ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_packed_weights_bwd_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
              "ngp_ffmlp_backward_workspace": _sz, "ngp_ffmlp_backward_buffer_bytes": _sz, "ngp_render_upsample_workspace": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
 
 _lib = None

@@ -108,9 +108,14 @@ struct NetArgs {
     uint32_t cell_steps;
     uint32_t cell_off[16];     // first record of a level
     uint32_t dbg_shrink;       // diagnostics (debug flag bits 4-7): fold hashed levels into size >> n entries (timing only, wrong images)
+    uint32_t f32;              // ngp_model::precision == NGP_PREC_F32: `table` holds float pairs, `packed` float fragments (NetF32 below)
 };
 
 __host__ __device__ inline uint32_t sig_halfs(uint32_t mm) { return 2048 + mm * 4096 + 1024; }
+// bytes of the packed forward weights of both nets (the LDS image every fused kernel starts with)
+__host__ __device__ inline size_t net_w_bytes(const NetArgs& na) {
+    return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * (na.f32 ? 4 : 2);
+}
 
 // ------------------------------------------------------------------------------------------
 // weight fragment packing.  Source blobs are FFMLP-layout [64 x 32 | mm x 64 x 64 | 16 x 64].
@@ -500,9 +505,239 @@ __device__ __forceinline__ void net_tile(const NetArgs& na, const _Float16* Wlds
     net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
 }
 
+// ==========================================================================================
+// The same network in fp32 (ngp_model::precision == NGP_PREC_F32): what validate.py's rollout evaluates.  Its render_fn is a bare
+// model.render(...) (validate.py:288-291) -- no autocast context is ever entered on that path (the only ones are inside Trainer
+// methods, nerf/utils.py:544-864) -- so the table is read as fp32 (gridencoder/grid.py:36-39 casts only under autocast) and the
+// nn.Linear layers of nerf/network.py:33-47 run as fp32 GEMMs.
+//
+// Same lane mapping as the fp16 form: lane = (sample c, quarter q), a lane gathers levels q, q+4, q+8, q+12 as 8-byte (float2)
+// entries and interpolates them with the operator's arithmetic (fmaf(w, entry, acc) over the corners in index order,
+// gridencoder.cu:139-175: the features are bit-identical to grid_encode's fp32 output).  The MLPs run on v_mfma_f32_16x16x4_f32
+// (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, at the fp32 vector rate): H^T = W X^T again, so an accumulator
+// (units 16 ob + 4 q + r of sample c) is directly the B operand of the next layer's k-steps -- step (ob, r) takes register r of
+// block ob from every lane, i.e. k = q <-> unit 16 ob + 4 q + r -- and the A fragments are stored in that order:
+//   in layer  [ob 4][g 2][lane][4]: W_in[16 ob + c][phi(q, 4 g + r)],  phi = perm_grid / perm_color (the lane's own 8 inputs)
+//   hidden    [ob 4][g 4][lane][4]: W[16 ob + c][16 g + 4 q + r]
+//   out layer        [g 4][lane][4]: W_out[c][16 g + 4 q + r]
+// one ds_read_b128 per lane and four MFMAs.  The summation order over k is therefore a permutation of the natural one (fp32
+// round-off level, like any GEMM library's).  Source blobs: the FFMLP layout in fp32.
+// ==========================================================================================
+__global__ void k_pack_weights_f32(const float* __restrict__ sig, uint32_t sig_mm, const float* __restrict__ col, uint32_t col_mm,
+                                   float* __restrict__ packed) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_sig = sig_halfs(sig_mm), n_col = sig_halfs(col_mm);
+    if (e >= n_sig + n_col) return;
+    const bool is_col = e >= n_sig;
+    const uint32_t r = is_col ? e - n_sig : e;
+    const uint32_t mm = is_col ? col_mm : sig_mm;
+    const float* src = is_col ? col : sig;
+    const uint32_t r4 = r & 3, lane = (r >> 2) & 63, c = lane & 15, q = lane >> 4;
+    uint32_t src_idx;
+    if (r < 2048) {                                   // input layer [ob][g][lane][4]
+        const uint32_t blk = r >> 8, ob = blk >> 1, g = blk & 1, j = 4 * g + r4;
+        src_idx = (16 * ob + c) * 32 + (is_col ? perm_color(q, j) : perm_grid(q, j));
+    } else if (r < 2048 + mm * 4096) {                // hidden layers [k][ob][g][lane][4]
+        const uint32_t rr = r - 2048, layer = rr >> 12, blk = (rr & 4095) >> 8, ob = blk >> 2, g = blk & 3;
+        src_idx = 2048 + layer * 4096 + (16 * ob + c) * 64 + 16 * g + 4 * q + r4;
+    } else {                                          // output layer [g][lane][4]
+        const uint32_t g = (r - 2048 - mm * 4096) >> 8;
+        src_idx = 2048 + mm * 4096 + c * 64 + 16 * g + 4 * q + r4;
+    }
+    packed[e] = src[src_idx];
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void relu4(f32x4 (&h)[4]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[ob][r] = h[ob][r] > 0.0f ? h[ob][r] : 0.0f;
+}
+__device__ __forceinline__ void mlp32_in(const f32x4* W, uint32_t lane, const float (&x)[8], f32x4 (&h)[4]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) h[ob] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        f32x4 a[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++) a[ob] = W[(ob * 2 + g) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int ob = 0; ob < 4; ob++) h[ob] = mfma4(a[ob][r], x[4 * g + r], h[ob]);
+    }
+    relu4(h);
+}
+__device__ __forceinline__ void mlp32_hidden_raw(const f32x4* W, uint32_t lane, const f32x4 (&h)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) acc[ob] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        f32x4 a[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++) a[ob] = W[(ob * 4 + g) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int ob = 0; ob < 4; ob++) acc[ob] = mfma4(a[ob][r], h[g][r], acc[ob]);
+    }
+}
+__device__ __forceinline__ void mlp32_hidden(const f32x4* W, uint32_t lane, f32x4 (&h)[4]) {
+    f32x4 acc[4];
+    mlp32_hidden_raw(W, lane, h, acc);
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) h[ob] = acc[ob];
+    relu4(h);
+}
+__device__ __forceinline__ f32x4 mlp32_out(const f32x4* W, uint32_t lane, const f32x4 (&h)[4]) {
+    f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const f32x4 a = W[g * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++) o = mfma4(a[r], h[g][r], o);
+    }
+    return o;
+}
+
+// a lane's four levels from the fp32 table: 32 eight-byte corner entries, the interpolation fractions, the out-of-range flag
+template <int MODE>
+__device__ __forceinline__ void fused_gather32(const NetArgs& na, const LevelTab& lt, uint32_t q, float x, float y, float z, float2 (&raw)[4][8],
+                                               float (&fr)[4][3], bool& oob) {
+    float u[3];
+    encoder_unit(na, x, y, z, u, oob);
+    const float half_off = na.align_corners ? 0.0f : 0.5f;
+    const float2* table = reinterpret_cast<const float2*>(na.table);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t level = q + 4 * i;
+        const float scale = lt.scale[level];
+        uint32_t g[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float p = fmaf(u[d], scale, half_off);
+            g[d] = (uint32_t)floorf(p);
+            fr[i][d] = p - (float)g[d];
+        }
+        const float2* tab = table + lt.offset[level];
+        const uint32_t a1 = lt.a1[level], a2 = lt.a2[level], mask = lt.mask[level], fl = lt.flags[level];
+        const bool hashed = (fl & 1u) != 0;
+        const uint32_t t1[2] = {g[1] * a1, g[1] * a1 + a1}, t2[2] = {g[2] * a2, g[2] * a2 + a2};
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const uint32_t px = g[0] + (idx & 1), ty = t1[(idx >> 1) & 1], tz = t2[(idx >> 2) & 1];
+            uint32_t e = hashed ? (px ^ ty ^ tz) : (px + ty + tz);
+            e &= mask;
+            if (MODE == 1) { if (fl & 2u) e %= lt.size[level]; }
+            raw[i][idx] = tab[e];
+        }
+    }
+}
+// gridencoder.cu:139-175 in fp32: results[ch] += w * grid[index + ch] over the corners in index order (one fma each under nvcc's
+// -fmad; the operator and the oracle write it as fmaf) -- bit-identical to grid_encode's fp32 features
+__device__ __forceinline__ void corners_to_feature32(const float (&fr)[3], const float2 (&raw)[8], bool oob, float& f0, float& f1) {
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const float wx = (idx & 1) ? fr[0] : 1 - fr[0];
+        const float wy = (idx & 2) ? fr[1] : 1 - fr[1];
+        const float wz = (idx & 4) ? fr[2] : 1 - fr[2];
+        const float w = (wx * wy) * wz;
+        a0 = fmaf(w, raw[idx].x, a0);
+        a1 = fmaf(w, raw[idx].y, a1);
+    }
+    f0 = oob ? 0.0f : a0;
+    f1 = oob ? 0.0f : a1;
+}
+// d feature / d u_gd of one level (gridencoder.cu:177-222) contracted with the feature gradients (g0, g1): += into gx[3]
+__device__ __forceinline__ void level_input_grad32(float scale, const float (&fr)[3], const float2 (&raw)[8], float g0, float g1, float (&gx)[3]) {
+#pragma unroll
+    for (int gd = 0; gd < 3; gd++) {
+        float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            float w = scale;
+            int left = 0;
+#pragma unroll
+            for (int nd = 0; nd < 2; nd++) {
+                const int d = (nd >= gd) ? (nd + 1) : nd;
+                const int bit = (k4 >> nd) & 1;
+                w *= bit ? fr[d] : 1 - fr[d];
+                left |= bit << d;
+            }
+            const int right = left | (1 << gd);
+            d0 = fmaf(w, raw[right].x - raw[left].x, d0);
+            d1 = fmaf(w, raw[right].y - raw[left].y, d1);
+        }
+        gx[gd] = fmaf(g0, d0, fmaf(g1, d1, gx[gd]));
+    }
+}
+
+// backward fragments, fp32.  Per net: [out layer: ob 4][lane][4] | [hidden layers, LAST first: ob 4][g 4][lane][4] | [in layer: ob 2][g 4][lane][4]
+//   out layer   : A[row = unit 16 ob + c][k = q] of step r = W_out[4 q + r][unit]            (B operand = the lane's output gradient r)
+//   hidden layer: A[row = unit 16 ob + c of the layer BELOW][k = q] of step (g, r) = W[16 g + 4 q + r][that unit]
+//   in layer    : accumulator (ob, r) of lane (c, q') = gradient of the lane's own input 4 ob + r, i.e. of feature phi(q', 4 ob + r):
+//                 A[row i][k = q] of step (g, r) = W_in[16 g + 4 q + r][phi(i >> 2, 4 ob + (i & 3))]
+__host__ __device__ inline uint32_t bwd_floats(uint32_t mm) { return 1024 + mm * 4096 + 2048; }
+__global__ void k_pack_weights_bwd_f32(const float* __restrict__ sig, uint32_t sig_mm, const float* __restrict__ col, uint32_t col_mm,
+                                       float* __restrict__ packed) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_sig = bwd_floats(sig_mm), n_col = bwd_floats(col_mm);
+    if (e >= n_sig + n_col) return;
+    const bool is_col = e >= n_sig;
+    const uint32_t r = is_col ? e - n_sig : e;
+    const uint32_t mm = is_col ? col_mm : sig_mm;
+    const float* src = is_col ? col : sig;
+    const uint32_t r4 = r & 3, lane = (r >> 2) & 63, c = lane & 15, q = lane >> 4;
+    const uint32_t w_hid = 2048, w_out = 2048 + mm * 4096;
+    float v;
+    if (r < 1024) {                                                   // out layer [ob][lane][4]
+        const uint32_t ob = r >> 8;
+        v = src[w_out + (4 * q + r4) * 64 + 16 * ob + c];
+    } else if (r < 1024 + mm * 4096) {                                // hidden layers, last first
+        const uint32_t rr = r - 1024, slot = rr >> 12, blk = (rr & 4095) >> 8, ob = blk >> 2, g = blk & 3;
+        const uint32_t layer = mm - 1 - slot;
+        v = src[w_hid + layer * 4096 + (16 * g + 4 * q + r4) * 64 + 16 * ob + c];
+    } else {                                                          // in layer [ob 2][g 4][lane][4]
+        const uint32_t blk = (r - 1024 - mm * 4096) >> 8, ob = blk >> 2, g = blk & 3;
+        const uint32_t qq = c >> 2, jj = 4 * ob + (c & 3);
+        v = src[(16 * g + 4 * q + r4) * 32 + (is_col ? perm_color(qq, jj) : perm_grid(qq, jj))];
+    }
+    packed[e] = v;
+}
+__device__ __forceinline__ void mlp32_out_bwd(const f32x4* Wt, uint32_t lane, const f32x4& g, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++) {
+        const f32x4 a = Wt[ob * 64 + lane];
+        acc[ob] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[ob] = mfma4(a[r], g[r], acc[ob]);
+    }
+}
+__device__ __forceinline__ void mlp32_in_bwd(const f32x4* Wt, uint32_t lane, const f32x4 (&g)[4], f32x4 (&acc)[2]) {
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++) acc[ob] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int gg = 0; gg < 4; gg++)
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++) {
+            const f32x4 a = Wt[(ob * 4 + gg) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[ob] = mfma4(a[r], g[gg][r], acc[ob]);
+        }
+}
+// gradient through ReLU at the layer whose post-activation forward values are h
+__device__ __forceinline__ void relu_mask32(const f32x4 (&acc)[4], const f32x4 (&h)[4], f32x4 (&g)[4]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) g[ob][r] = h[ob][r] > 0.0f ? acc[ob][r] : 0.0f;
+}
+
 // stage packed weights + level table into LDS (all threads of the block)
-__device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels& lv, _Float16* Wlds, LevelTab* lt) {
-    const uint32_t n16 = (sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) / 8;  // 16-byte chunks
+__device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels& lv, void* Wlds, LevelTab* lt) {
+    const uint32_t n16 = (uint32_t)(net_w_bytes(na) / 16);  // 16-byte chunks
     const uint4* src = reinterpret_cast<const uint4*>(na.packed);
     uint4* dst = reinterpret_cast<uint4*>(Wlds);
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
@@ -522,13 +757,320 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------
+// Network policies: what a fused kernel needs of the network, for the two precisions.  `W` is the LDS image of the packed forward
+// weights (sigma net, then colour net), `Wb` that of the transposed ones (backward kernels only).
+//   density      hash grid + sigma net of the lane's sample -> sigma (trunc_exp output, meaningful in q == 0) and the sigma net's
+//                outputs 4q..4q+3 (`geo_t`: fp16 / fp32)
+//   color        SH + colour net -> rgb in q == 0
+//   density_tape the same forward keeping what its backward needs;  density_vjp: dL/d(sigma-net outputs) -> this lane's part of
+//                dL/d(encoder input in [0,1]) (the sample's is the sum over its four lanes)
+//   color_vjp    colour net forward + backward for one tile: dL/d rgb = G * wsc * sigmoid' -> this lane's part of dL/d dir (through
+//                SH) and dL/d(sigma-net outputs) (through the geometry features)
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t bwd_halfs(uint32_t mm);
+__device__ __forceinline__ void mlp_out_bwd(const half8* Wt, uint32_t lane, half8 g, f32x4 (&acc)[4]);
+__device__ __forceinline__ void mlp_hidden_bwd(const half8* Wt, uint32_t lane, const half8 (&g)[2], f32x4 (&acc)[4]);
+__device__ __forceinline__ void mlp_in_bwd(const half8* Wt, uint32_t lane, const half8 (&g)[2], f32x4 (&acc)[2]);
+__device__ __forceinline__ void relu_mask_pack(const f32x4 (&acc)[4], const half8 (&h)[2], half8 (&g)[2]);
+__device__ __forceinline__ void sh4_quarter_vjp(uint32_t q, float x, float y, float z, const float (&g)[4], float (&o)[3]);
+
+template <int MODE_>
+struct NetF16 {
+    static constexpr int MODE = MODE_;
+    static constexpr bool kF32 = false;
+    typedef _Float16 geo_t;
+    static __device__ __forceinline__ void density(const NetArgs& na, const char* W, const LevelTab& lt, uint32_t lane, float x, float y, float z,
+                                                   float& sigma, geo_t (&s)[4]) {
+        net_density<MODE>(na, reinterpret_cast<const _Float16*>(W), lt, lane, x, y, z, sigma, s);
+    }
+    static __device__ __forceinline__ void color(const NetArgs& na, const char* W, uint32_t lane, float dx, float dy, float dz, const geo_t (&s)[4],
+                                                 float& cr, float& cg, float& cb) {
+        net_color(na, reinterpret_cast<const _Float16*>(W), lane, dx, dy, dz, s, cr, cg, cb);
+    }
+    static __host__ __device__ size_t wb_bytes(const NetArgs& na) { return (size_t)(bwd_halfs(na.sig_mm) + bwd_halfs(na.col_mm)) * 2; }
+
+    struct Tape {
+        bool oob;
+        uint32_t raw[4][8];
+        float fr[4][3], scl[4];
+        half8 hs[3][2], hs_last[2];        // sigma net: post-activations of the input layer and of each hidden layer
+    };
+    static __device__ __forceinline__ void density_tape(const NetArgs& na, const char* W, const LevelTab& lt, uint32_t lane, float x, float y,
+                                                        float z, Tape& t, geo_t (&s)[4]) {
+        const uint32_t q = lane >> 4;
+        const half8* Ws = reinterpret_cast<const half8*>(W);
+        fused_gather<MODE>(na, lt, q, x, y, z, t.raw, t.fr, t.oob);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t.scl[i] = lt.scale[q + 4 * i];
+        half8 feat;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            _Float16 f0, f1;
+            corners_to_feature(t.fr[i], t.raw[i], t.oob, f0, f1);
+            feat[2 * i] = f0; feat[2 * i + 1] = f1;
+        }
+        mlp_in(Ws, lane, feat, t.hs[0]);                   // (indices stay compile-time constants: register arrays)
+        t.hs_last[0] = t.hs[0][0]; t.hs_last[1] = t.hs[0][1];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if ((uint32_t)k < na.sig_mm) {
+                mlp_hidden(Ws + 256 + k * 512, lane, t.hs_last);
+                t.hs[k + 1][0] = t.hs_last[0]; t.hs[k + 1][1] = t.hs_last[1];
+            }
+        const f32x4 so = mlp_out(Ws + 256 + na.sig_mm * 512, lane, t.hs_last);
+#pragma unroll
+        for (int r = 0; r < 4; r++) s[r] = (_Float16)so[r];
+    }
+    static __device__ __forceinline__ void density_vjp(const NetArgs& na, const char* Wb, uint32_t lane, const Tape& t, const f32x4& gso,
+                                                       float (&gx)[3]) {
+        const half8* Bs = reinterpret_cast<const half8*>(Wb);
+        half8 gs_out = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) gs_out[r] = (_Float16)gso[r];
+        f32x4 acc[4];
+        half8 gsn[2];
+        mlp_out_bwd(Bs, lane, gs_out, acc);
+        relu_mask_pack(acc, t.hs_last, gsn);
+#pragma unroll
+        for (int l = 1; l >= 0; l--)
+            if ((uint32_t)l < na.sig_mm) {
+                mlp_hidden_bwd(Bs + 256 + (na.sig_mm - 1 - l) * 512, lane, gsn, acc);
+                relu_mask_pack(acc, t.hs[l], gsn);
+            }
+        f32x4 gfe[2];
+        mlp_in_bwd(Bs + 256 + na.sig_mm * 512, lane, gsn, gfe);
+        // accumulator (ob, r) = gradient of feature perm_grid(q, 4 ob + r) = level q + 4 (2 ob + (r >> 1)), channel r & 1
+        gx[0] = 0; gx[1] = 0; gx[2] = 0;
+        if (!t.oob) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float g0 = (float)(_Float16)gfe[i >> 1][2 * (i & 1)], g1 = (float)(_Float16)gfe[i >> 1][2 * (i & 1) + 1];
+#pragma unroll
+                for (int gd = 0; gd < 3; gd++) {              // gridencoder.cu:177-222: d feature / d u_gd = scale * sum_4 w (right - left)
+                    float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; k4++) {
+                        float w = t.scl[i];
+                        int left = 0;
+#pragma unroll
+                        for (int nd = 0; nd < 2; nd++) {
+                            const int d = (nd >= gd) ? (nd + 1) : nd;
+                            const int bit = (k4 >> nd) & 1;
+                            w *= bit ? t.fr[i][d] : 1 - t.fr[i][d];
+                            left |= bit << d;
+                        }
+                        const int right = left | (1 << gd);
+                        const uint32_t rl = t.raw[i][left], rr = t.raw[i][right];
+                        d0 = fmaf(w, (float)__builtin_bit_cast(_Float16, (uint16_t)(rr & 0xffffu)) - (float)__builtin_bit_cast(_Float16, (uint16_t)(rl & 0xffffu)), d0);
+                        d1 = fmaf(w, (float)__builtin_bit_cast(_Float16, (uint16_t)(rr >> 16)) - (float)__builtin_bit_cast(_Float16, (uint16_t)(rl >> 16)), d1);
+                    }
+                    gx[gd] = fmaf(g0, d0, fmaf(g1, d1, gx[gd]));
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ void color_vjp(const NetArgs& na, const char* W, const char* Wb, uint32_t lane, float dx, float dy, float dz,
+                                                     const geo_t (&s)[4], float wsc, const float (&G)[3], float (&gdir)[3], f32x4& gso) {
+        const uint32_t q = lane >> 4;
+        const half8* Wc = reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(W) + sig_halfs(na.sig_mm));
+        const half8* Bc = reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(Wb) + bwd_halfs(na.sig_mm));
+        // ---- colour net forward with kept activations
+        float sh[4];
+        sh4_quarter(q, dx, dy, dz, sh);
+        half8 cin;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cin[r] = (_Float16)sh[r]; cin[4 + r] = s[r]; }
+        if (q == 0) cin[4] = (_Float16)0;
+        half8 hc[4][2], hc_last[2];
+        mlp_in(Wc, lane, cin, hc[0]);
+        hc_last[0] = hc[0][0]; hc_last[1] = hc[0][1];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if ((uint32_t)k < na.col_mm) {
+                mlp_hidden(Wc + 256 + k * 512, lane, hc_last);
+                hc[k + 1][0] = hc_last[0]; hc[k + 1][1] = hc_last[1];
+            }
+        const f32x4 co = mlp_out(Wc + 256 + na.col_mm * 512, lane, hc_last);
+        // ---- backward: sigmoid (on the fp16-rounded value, as torch.sigmoid's backward does), out layer, hidden, in
+        half8 gco = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q == 0) {
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const float yv = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[k3])));
+                gco[k3] = (_Float16)(G[k3] * wsc * (yv * (1.0f - yv)));
+            }
+        }
+        f32x4 acc[4];
+        half8 gc[2];
+        mlp_out_bwd(Bc, lane, gco, acc);
+        relu_mask_pack(acc, hc_last, gc);
+#pragma unroll
+        for (int l = 2; l >= 0; l--)                        // through hidden matmul l (input activations hc[l]), last first
+            if ((uint32_t)l < na.col_mm) {
+                mlp_hidden_bwd(Bc + 256 + (na.col_mm - 1 - l) * 512, lane, gc, acc);
+                relu_mask_pack(acc, hc[l], gc);
+            }
+        f32x4 gin[2];
+        mlp_in_bwd(Bc + 256 + na.col_mm * 512, lane, gc, gin);
+        // accumulator (ob, r) = gradient of colour input perm_color(q, 4 ob + r): ob 0 -> SH 4q + r, ob 1 -> sigma-net output 4q + r
+        const float gsh[4] = {(float)(_Float16)gin[0][0], (float)(_Float16)gin[0][1], (float)(_Float16)gin[0][2], (float)(_Float16)gin[0][3]};
+        sh4_quarter_vjp(q, dx, dy, dz, gsh, gdir);
+#pragma unroll
+        for (int r = 0; r < 4; r++) gso[r] = (float)(_Float16)gin[1][r];
+        if (q == 0) gso[0] = 0.0f;                          // that slot was the zero pad, not sigma
+    }
+};
+
+template <int MODE_>
+struct NetF32 {
+    static constexpr int MODE = MODE_;
+    static constexpr bool kF32 = true;
+    typedef float geo_t;
+    static __device__ __forceinline__ void features(const NetArgs& na, const LevelTab& lt, uint32_t q, float x, float y, float z, float (&feat)[8]) {
+        float2 raw[4][8];
+        float fr[4][3];
+        bool oob;
+        fused_gather32<MODE>(na, lt, q, x, y, z, raw, fr, oob);
+#pragma unroll
+        for (int i = 0; i < 4; i++) corners_to_feature32(fr[i], raw[i], oob, feat[2 * i], feat[2 * i + 1]);
+    }
+    static __device__ __forceinline__ void density(const NetArgs& na, const char* W, const LevelTab& lt, uint32_t lane, float x, float y, float z,
+                                                   float& sigma, geo_t (&s)[4]) {
+        const f32x4* Ws = reinterpret_cast<const f32x4*>(W);
+        float feat[8];
+        features(na, lt, lane >> 4, x, y, z, feat);
+        f32x4 h[4];
+        mlp32_in(Ws, lane, feat, h);
+        for (uint32_t k = 0; k < na.sig_mm; k++) mlp32_hidden(Ws + 512 + k * 1024, lane, h);
+        const f32x4 so = mlp32_out(Ws + 512 + na.sig_mm * 1024, lane, h);
+#pragma unroll
+        for (int r = 0; r < 4; r++) s[r] = so[r];
+        sigma = expf(so[0]);              // trunc_exp forward (activation.py:8-10), meaningful in q == 0
+    }
+    static __device__ __forceinline__ void color_input(uint32_t q, float dx, float dy, float dz, const geo_t (&s)[4], float (&cin)[8]) {
+        float sh[4];
+        sh4_quarter(q, dx, dy, dz, sh);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cin[r] = sh[r]; cin[4 + r] = s[r]; }
+        if (q == 0) cin[4] = 0.0f;        // lane 0's accumulator row 0 is sigma, not a feature: this slot meets the zero-padded weight column
+    }
+    static __device__ __forceinline__ void color(const NetArgs& na, const char* W, uint32_t lane, float dx, float dy, float dz, const geo_t (&s)[4],
+                                                 float& cr, float& cg, float& cb) {
+        const f32x4* Wc = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(W) + sig_halfs(na.sig_mm));
+        float cin[8];
+        color_input(lane >> 4, dx, dy, dz, s, cin);
+        f32x4 h[4];
+        mlp32_in(Wc, lane, cin, h);
+        for (uint32_t k = 0; k < na.col_mm; k++) mlp32_hidden(Wc + 512 + k * 1024, lane, h);
+        const f32x4 co = mlp32_out(Wc + 512 + na.col_mm * 1024, lane, h);
+        cr = 1.0f / (1.0f + expf(-co[0]));                 // torch.sigmoid (nerf/network.py:122)
+        cg = 1.0f / (1.0f + expf(-co[1]));
+        cb = 1.0f / (1.0f + expf(-co[2]));
+    }
+    static __host__ __device__ size_t wb_bytes(const NetArgs& na) { return (size_t)(bwd_floats(na.sig_mm) + bwd_floats(na.col_mm)) * 4; }
+
+    // backward kernels: at most 1 hidden matmul in the sigma net and 2 in the colour net (nerf/network.py has 0 and 1)
+    static constexpr uint32_t kMaxSigMM = 1, kMaxColMM = 2;
+    struct Tape {
+        bool oob;
+        float2 raw[4][8];
+        float fr[4][3], scl[4];
+        f32x4 hs[2][4], hs_last[4];
+    };
+    static __device__ __forceinline__ void density_tape(const NetArgs& na, const char* W, const LevelTab& lt, uint32_t lane, float x, float y,
+                                                        float z, Tape& t, geo_t (&s)[4]) {
+        const uint32_t q = lane >> 4;
+        const f32x4* Ws = reinterpret_cast<const f32x4*>(W);
+        fused_gather32<MODE>(na, lt, q, x, y, z, t.raw, t.fr, t.oob);
+        float feat[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            t.scl[i] = lt.scale[q + 4 * i];
+            corners_to_feature32(t.fr[i], t.raw[i], t.oob, feat[2 * i], feat[2 * i + 1]);
+        }
+        mlp32_in(Ws, lane, feat, t.hs[0]);
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++) t.hs_last[ob] = t.hs[0][ob];
+        if (na.sig_mm > 0) {
+            mlp32_hidden(Ws + 512, lane, t.hs_last);
+#pragma unroll
+            for (int ob = 0; ob < 4; ob++) t.hs[1][ob] = t.hs_last[ob];
+        }
+        const f32x4 so = mlp32_out(Ws + 512 + na.sig_mm * 1024, lane, t.hs_last);
+#pragma unroll
+        for (int r = 0; r < 4; r++) s[r] = so[r];
+    }
+    static __device__ __forceinline__ void density_vjp(const NetArgs& na, const char* Wb, uint32_t lane, const Tape& t, const f32x4& gso,
+                                                       float (&gx)[3]) {
+        const f32x4* Bs = reinterpret_cast<const f32x4*>(Wb);
+        f32x4 acc[4], g[4];
+        mlp32_out_bwd(Bs, lane, gso, acc);
+        relu_mask32(acc, t.hs_last, g);
+        if (na.sig_mm > 0) {
+            mlp32_hidden_raw(Bs + 256, lane, g, acc);      // (the transposed fragments have the forward layout: rows = units of the layer below)
+            relu_mask32(acc, t.hs[0], g);
+        }
+        f32x4 gfe[2];
+        mlp32_in_bwd(Bs + 256 + na.sig_mm * 1024, lane, g, gfe);
+        gx[0] = 0; gx[1] = 0; gx[2] = 0;
+        if (!t.oob) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) level_input_grad32(t.scl[i], t.fr[i], t.raw[i], gfe[i >> 1][2 * (i & 1)], gfe[i >> 1][2 * (i & 1) + 1], gx);
+        }
+    }
+    static __device__ __forceinline__ void color_vjp(const NetArgs& na, const char* W, const char* Wb, uint32_t lane, float dx, float dy, float dz,
+                                                     const geo_t (&s)[4], float wsc, const float (&G)[3], float (&gdir)[3], f32x4& gso) {
+        const uint32_t q = lane >> 4;
+        const f32x4* Wc = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(W) + sig_halfs(na.sig_mm));
+        const f32x4* Bc = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Wb) + bwd_floats(na.sig_mm));
+        float cin[8];
+        color_input(q, dx, dy, dz, s, cin);
+        f32x4 hc[3][4], hc_last[4];
+        mlp32_in(Wc, lane, cin, hc[0]);
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++) hc_last[ob] = hc[0][ob];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if ((uint32_t)k < na.col_mm) {
+                mlp32_hidden(Wc + 512 + k * 1024, lane, hc_last);
+#pragma unroll
+                for (int ob = 0; ob < 4; ob++) hc[k + 1][ob] = hc_last[ob];
+            }
+        const f32x4 co = mlp32_out(Wc + 512 + na.col_mm * 1024, lane, hc_last);
+        f32x4 gco = {0, 0, 0, 0};
+        if (q == 0) {
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const float yv = 1.0f / (1.0f + expf(-co[k3]));
+                gco[k3] = G[k3] * wsc * (yv * (1.0f - yv));
+            }
+        }
+        f32x4 acc[4], gc[4];
+        mlp32_out_bwd(Bc, lane, gco, acc);
+        relu_mask32(acc, hc_last, gc);
+#pragma unroll
+        for (int l = 1; l >= 0; l--)
+            if ((uint32_t)l < na.col_mm) {
+                mlp32_hidden_raw(Bc + 256 + (na.col_mm - 1 - l) * 1024, lane, gc, acc);
+                relu_mask32(acc, hc[l], gc);
+            }
+        f32x4 gin[2];
+        mlp32_in_bwd(Bc + 256 + na.col_mm * 1024, lane, gc, gin);
+        const float gsh[4] = {gin[0][0], gin[0][1], gin[0][2], gin[0][3]};
+        sh4_quarter_vjp(q, dx, dy, dz, gsh, gdir);
+        gso = gin[1];
+        if (q == 0) gso[0] = 0.0f;                          // that slot was the zero pad, not sigma
+    }
+};
+
 // Diagnostics: the 32 hash-grid features as the fused kernels form them ([M, 32] fp16 in the operator's order 2 * level + channel),
 // with the default arithmetic or with the operator's (HALF_ACC)
 template <int MODE, bool HALF_ACC>
 __global__ void __launch_bounds__(256) k_debug_features(NetArgs na, GridLevels lv, const float* __restrict__ xyzs, uint32_t M, _Float16* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
     stage_block(na, lv, Wlds, lt);
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -547,17 +1089,35 @@ __global__ void __launch_bounds__(256) k_debug_features(NetArgs na, GridLevels l
     }
 }
 
+template <int MODE>
+__global__ void __launch_bounds__(256) k_debug_features32(NetArgs na, GridLevels lv, const float* __restrict__ xyzs, uint32_t M, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
+    stage_block(na, lv, smem, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t tile = wave; tile < (M + 15) / 16; tile += n_waves) {
+        const uint32_t m = tile * 16 + c, mm = m < M ? m : M - 1;
+        float feat[8];
+        NetF32<MODE>::features(na, *lt, q, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], feat);
+        if (m < M) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { out[(size_t)m * 32 + 2 * (q + 4 * i)] = feat[2 * i]; out[(size_t)m * 32 + 2 * (q + 4 * i) + 1] = feat[2 * i + 1]; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NeRFNetwork.forward on an explicit point list (network_ff.py:51-75)
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+template <class NET>
 __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels lv, const float* __restrict__ xyzs,
                                                          const float* __restrict__ dirs, uint32_t M, float* __restrict__ sigmas,
                                                          float* __restrict__ rgbs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
-    stage_block(na, lv, Wlds, lt);
+    const char* Wlds = smem;
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
+    stage_block(na, lv, smem, lt);
     const uint32_t lane = threadIdx.x & 63, c = lane & 15;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_tiles = (M + 15) / 16;
@@ -565,8 +1125,9 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
         const uint32_t m = tile * 16 + c;
         const uint32_t mm = m < M ? m : M - 1;
         float sg, r, g, b;
-        net_tile<MODE>(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], dirs[(size_t)mm * 3],
-                 dirs[(size_t)mm * 3 + 1], dirs[(size_t)mm * 3 + 2], sg, r, g, b);
+        typename NET::geo_t s16[4];
+        NET::density(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], sg, s16);
+        NET::color(na, Wlds, lane, dirs[(size_t)mm * 3], dirs[(size_t)mm * 3 + 1], dirs[(size_t)mm * 3 + 2], s16, r, g, b);
         if (lane < 16 && m < M) {
             sigmas[m] = sg;
             rgbs[(size_t)m * 3] = r;
@@ -577,23 +1138,82 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
 }
 
 // the density half alone (NeRFNetwork.density, network_ff.py:77-90): what the density-grid maintenance queries (renderer.py:487,526)
-template <int MODE>
+// geo (optional, [M, 15] f32): the geometry features = the sigma net's outputs 1..15 (what density() returns next to sigma)
+template <class NET>
 __global__ void __launch_bounds__(256) k_network_density(NetArgs na, GridLevels lv, const float* __restrict__ xyzs, uint32_t M,
-                                                         float* __restrict__ sigmas) {
+                                                         float* __restrict__ sigmas, float* __restrict__ geo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
-    stage_block(na, lv, Wlds, lt);
-    const uint32_t lane = threadIdx.x & 63, c = lane & 15;
+    const char* Wlds = smem;
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
+    stage_block(na, lv, smem, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_tiles = (M + 15) / 16;
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t m = tile * 16 + c;
         const uint32_t mm = m < M ? m : M - 1;
         float sg;
-        _Float16 s16[4];
-        net_density<MODE>(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], sg, s16);
+        typename NET::geo_t s16[4];
+        NET::density(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], sg, s16);
         if (lane < 16 && m < M) sigmas[m] = sg;
+        if (geo && m < M) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * q + r > 0) geo[(size_t)m * 15 + 4 * q + r - 1] = (float)s16[r];
+        }
+    }
+}
+
+// Vector-Jacobian product of the density half with respect to the POINTS, map frozen: what the trajectory planner differentiates
+// (nav/quad_plot.py:223-249: density_fn on S x 500 body points, 250 Adam steps per simulator step).  Upstream gradients of sigma [M]
+// and (optional) of the geometry features [M, 15] -> grad_xyzs [M, 3].  One pass: forward with kept activations, trunc_exp backward
+// (activation.py:12-17), the transposed sigma net, the hash grid's input derivative, d u / d x = 1 / (2 bound).
+template <class NET>
+__global__ void __launch_bounds__(256) k_network_density_bwd(NetArgs na, GridLevels lv, const char* __restrict__ packed_bwd,
+                                                             const float* __restrict__ xyzs, uint32_t M, const float* __restrict__ g_sigma,
+                                                             const float* __restrict__ g_geo, float* __restrict__ grad_xyzs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t w_bytes = net_w_bytes(na);
+    const size_t ws_bytes = NET::kF32 ? (size_t)bwd_floats(na.sig_mm) * 4 : (size_t)bwd_halfs(na.sig_mm) * 2;   // the sigma net's transposed fragments only
+    const char* Wlds = smem;
+    char* Wb = smem + w_bytes;
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes + ws_bytes);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(packed_bwd);
+        uint4* dst = reinterpret_cast<uint4*>(Wb);
+        for (uint32_t i = threadIdx.x; i < ws_bytes / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    stage_block(na, lv, smem, lt);
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_tiles = (M + 15) / 16;
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t m = tile * 16 + c;
+        const bool valid = m < M;
+        const uint32_t mm = valid ? m : M - 1;
+        typename NET::Tape tape;
+        typename NET::geo_t s16[4];
+        NET::density_tape(na, Wlds, *lt, lane, xyzs[(size_t)mm * 3], xyzs[(size_t)mm * 3 + 1], xyzs[(size_t)mm * 3 + 2], tape, s16);
+        f32x4 gso = {0, 0, 0, 0};
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t o = 4 * q + r;
+                if (o == 0) gso[r] = g_sigma ? g_sigma[m] * expf(fminf(15.0f, fmaxf(-15.0f, (float)s16[0]))) : 0.0f;
+                else gso[r] = g_geo ? g_geo[(size_t)m * 15 + o - 1] : 0.0f;
+            }
+        }
+        float gx[3];
+        NET::density_vjp(na, Wb, lane, tape, gso, gx);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            gx[d] += __shfl_xor(gx[d], 16, 64);
+            gx[d] += __shfl_xor(gx[d], 32, 64);
+        }
+        if (lane < 16 && valid) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) grad_xyzs[(size_t)m * 3 + d] = gx[d] * na.inv_two_bound;
+        }
     }
 }
 
@@ -605,8 +1225,8 @@ __global__ void __launch_bounds__(256) k_network_density(NetArgs na, GridLevels 
 // weights, depth, colour and weights * sigma.  None of the reference's [N, T, *] intermediates exists in memory; the
 // per-sample sigmas / rgbs it returns for the LAST ray chunk are written only for rays >= dump_begin.
 // ------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
+template <class NET>
+__global__ void __launch_bounds__(256, NET::kF32 ? 2 : 4) k_render_uniform(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, const float* __restrict__ nears,
                                                            const float* __restrict__ fars, uint32_t N, uint32_t T,
                                                            const float* __restrict__ lin, float* __restrict__ weights_sum,
@@ -614,9 +1234,9 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
                                                            float* __restrict__ aggregated_density, uint32_t dump_begin,
                                                            float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
-    stage_block(na, lv, Wlds, lt);
+    const char* Wlds = smem;
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
+    stage_block(na, lv, smem, lt);
     const uint32_t lane = threadIdx.x & 63, c = lane & 15;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t ray = wave; ray < N; ray += n_waves) {
@@ -637,8 +1257,8 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
             const float y = clampf(oy + dy * zv, aabb_lo, aabb_hi);
             const float z = clampf(oz + dz * zv, aabb_lo, aabb_hi);
             float sigma;
-            _Float16 s16[4];
-            net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+            typename NET::geo_t s16[4];
+            NET::density(na, Wlds, *lt, lane, x, y, z, sigma, s16);
             // ---- lanes 0..15 hold sigma of samples i0..i0+15 (the other quarters compute along with them; only lane < 16 results are used)
             const float z_next = (ii + 1 < T) ? near + span * lin[ii + 1] : 0.0f;
             const float delta = (ii + 1 < T) ? z_next - zv : sample_dist;           // :206-207
@@ -656,7 +1276,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
             const bool masked = valid && w > 1e-4f;                                  // :216
             float cr = 0, cg = 0, cb = 0;
             if (__ballot(masked && lane < 16) != 0ull) {
-                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                NET::color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
                 if (!masked) { cr = 0; cg = 0; cb = 0; }
             }
             if (lane < 16 && valid) {
@@ -699,8 +1319,8 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform(NetArgs na, GridLevel
 constexpr uint32_t kUniformX16MinRays = 65536;      // (measured: section 4 of DESIGN.md)
 // DENS: the density pass alone -- sigma of every uniform sample of every ray into sigmas [N, T], no colour, no sums, no early stop
 // (the coarse pass of the importance resampling, ngp_density_uniform).
-template <int MODE, bool DENS = false>
-__global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
+template <class NET, bool DENS = false>
+__global__ void __launch_bounds__(256, NET::kF32 ? 2 : 4) k_render_uniform_x16(NetArgs na, GridLevels lv, const float* __restrict__ rays_o,
                                                                const float* __restrict__ rays_d, const float* __restrict__ nears,
                                                                const float* __restrict__ fars, uint32_t N, uint32_t T,
                                                                const float* __restrict__ lin, float* __restrict__ weights_sum,
@@ -710,9 +1330,9 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
                                                                uint32_t frame_w, unsigned long long* __restrict__ stamps,
                                                                const float* __restrict__ z_in, _Float16* __restrict__ geo_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
-    stage_block(na, lv, Wlds, lt);
+    const char* Wlds = smem;
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
+    stage_block(na, lv, smem, lt);
     const uint32_t lane = threadIdx.x & 63, c = lane & 15;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_groups = (N + 15) / 16;
@@ -734,7 +1354,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
         float a_ws = 0, a_dep = 0, a_r = 0, a_g = 0, a_b = 0, a_agg = 0;
         bool running = live;
         uint32_t n_iter = 0, n_counted = 0;
-        if (DENS) {      // z_in: the depths come from the resampling instead of the uniform table.  Scratch arrays are GROUP-major,
+        if constexpr (DENS && !NET::kF32) {      // z_in: the depths come from the resampling instead of the uniform table.  Scratch arrays are GROUP-major,
             // [group][sample][ray of the group]: the sixteen rays' values of one sample are 64 (sigma, depth) or 512 (geo) contiguous bytes
             for (uint32_t i = 0; i < T; i++) {
                 const size_t at = ((size_t)grp * T + i) * 16 + c;
@@ -742,7 +1362,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
                 const float x = clampf(ox + dx * zs, aabb_lo, aabb_hi), y = clampf(oy + dy * zs, aabb_lo, aabb_hi), z = clampf(oz + dz * zs, aabb_lo, aabb_hi);
                 float sigma;
                 _Float16 s16[4];
-                net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+                NET::density(na, Wlds, *lt, lane, x, y, z, sigma, s16);
                 if (lane < 16) sigmas[at] = sigma;
                 // the sigma net's sixteen outputs (sigma's pre-activation + the 15 geometry features), 4 per quarter: what the colour
                 // net of the compositing launch needs of this sample
@@ -761,8 +1381,8 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
             const float y = clampf(oy + dy * zv, aabb_lo, aabb_hi);
             const float z = clampf(oz + dz * zv, aabb_lo, aabb_hi);
             float sigma;
-            _Float16 s16[4];
-            net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+            typename NET::geo_t s16[4];
+            NET::density(na, Wlds, *lt, lane, x, y, z, sigma, s16);
             // (quarter 0 holds sigma; the other quarters evaluate other rows of the sigma net in `sigma` and follow quarter 0's
             //  decisions through the ballots below)
             const float delta = (i + 1 < T) ? z_next - zv : sample_dist;             // :206-207
@@ -772,7 +1392,7 @@ __global__ void __launch_bounds__(256, 4) k_render_uniform_x16(NetArgs na, GridL
             const bool masked = counted && w > 1e-4f;                                // :216
             float cr = 0, cg = 0, cb = 0;
             if (__ballot(masked) != 0ull) {
-                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                NET::color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
                 if (!masked) { cr = 0; cg = 0; cb = 0; }
             }
             if (counted) {
@@ -836,7 +1456,7 @@ __global__ void __launch_bounds__(256, 4) k_composite_merged_x16(NetArgs na, Gri
                                                                  float* __restrict__ sigmas, float* __restrict__ rgbs, uint32_t frame_w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
     stage_block(na, lv, Wlds, lt);
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -928,7 +1548,7 @@ __global__ void __launch_bounds__(256) k_render_upsample(NetArgs na, GridLevels 
     // sc_in: sigma of the uniform samples, evaluated by k_render_uniform_x16<DENS> (tiles across rays);  zf_out: stop after the resampling
     // and hand the new depths over.  Both group-major (frame_w as in that launch): the middle launch of the large-batch form.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
+    const size_t w_bytes = net_w_bytes(na);
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
     stage_block(na, lv, Wlds, lt);
@@ -1223,7 +1843,7 @@ struct GradArgs {
     const float *rays_o, *rays_d, *nears, *fars, *lin;
     const float *g_image, *g_depth, *g_ws, *g_agg;      // upstream gradients of the four per-ray outputs (g_depth / g_ws / g_agg may be NULL)
     float *grad_o, *grad_d;
-    const _Float16* packed_bwd;
+    const void* packed_bwd;
     uint32_t N, T;
     float aabb_lo, aabb_hi;
     float* dump;    // diagnostics (ngp_debug_set_grad_dump): [N][T][4] = sigma, transmittance, dL/dw, dL/dsigma per sample; NULL = off
@@ -1232,13 +1852,16 @@ struct GradArgs {
 constexpr int kGradWaves = 8;
 constexpr uint32_t kGradMaxT = 1024;
 
-template <int MODE>
-__global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetArgs na, GridLevels lv, GradArgs ga) {
+// GW waves (= rays in flight) per workgroup, one workgroup per CU: 8, or 4 -- one wave per SIMD with the whole register file, which the
+// fp32 form needs (its tape is twice the size) and which also spreads a small batch over all CUs (the pose estimator's 1024 rays are
+// 128 workgroups of 8 but 256 of 4)
+template <class NET, int GW>
+__global__ void __launch_bounds__(GW * 64, 1) k_render_uniform_bwd(NetArgs na, GridLevels lv, GradArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
-    const size_t wb_bytes = (size_t)(bwd_halfs(na.sig_mm) + bwd_halfs(na.col_mm)) * 2;
-    _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    _Float16* Wb = reinterpret_cast<_Float16*>(smem + w_bytes);
+    const size_t w_bytes = net_w_bytes(na);
+    const size_t wb_bytes = NET::wb_bytes(na);
+    const char* Wlds = smem;
+    char* Wb = smem + w_bytes;
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes + wb_bytes);
     float* store = reinterpret_cast<float*>(smem + w_bytes + wb_bytes + sizeof(LevelTab));
     {   // transposed fragments next to the forward ones
@@ -1246,18 +1869,14 @@ __global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetAr
         uint4* dst = reinterpret_cast<uint4*>(Wb);
         for (uint32_t i = threadIdx.x; i < wb_bytes / 16; i += blockDim.x) dst[i] = src[i];
     }
-    stage_block(na, lv, Wlds, lt);
+    stage_block(na, lv, smem, lt);
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const uint32_t T = ga.T;
     float* s_sig = store + (size_t)wid * 3 * T;      // pass 1: sigma (raw);  after the scan: dL/dsigma
     float* s_g = s_sig + T;                          // pass 1: dL/dw;        after the scan: w [w > 1e-4] (the scale of dL/drgb)
     float* s_T = s_g + T;                            // transmittance before the sample
-    const half8* Ws = reinterpret_cast<const half8*>(Wlds);
-    const half8* Wc = reinterpret_cast<const half8*>(Wlds + sig_halfs(na.sig_mm));
-    const half8* Bs = reinterpret_cast<const half8*>(Wb);
-    const half8* Bc = reinterpret_cast<const half8*>(Wb + bwd_halfs(na.sig_mm));
 
-    for (uint32_t ray = blockIdx.x * kGradWaves + wid; ray < ga.N; ray += gridDim.x * kGradWaves) {
+    for (uint32_t ray = blockIdx.x * GW + wid; ray < ga.N; ray += gridDim.x * GW) {
         const float ox = ga.rays_o[(size_t)ray * 3], oy = ga.rays_o[(size_t)ray * 3 + 1], oz = ga.rays_o[(size_t)ray * 3 + 2];
         const float dx = ga.rays_d[(size_t)ray * 3], dy = ga.rays_d[(size_t)ray * 3 + 1], dz = ga.rays_d[(size_t)ray * 3 + 2];
         const float near = ga.nears[ray], far = ga.fars[ray], span = far - near;
@@ -1275,8 +1894,8 @@ __global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetAr
             const float x = clampf(ox + dx * zv, ga.aabb_lo, ga.aabb_hi), y = clampf(oy + dy * zv, ga.aabb_lo, ga.aabb_hi),
                         z = clampf(oz + dz * zv, ga.aabb_lo, ga.aabb_hi);
             float sigma;
-            _Float16 s16[4];
-            net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sigma, s16);
+            typename NET::geo_t s16[4];
+            NET::density(na, Wlds, *lt, lane, x, y, z, sigma, s16);
             const float z_next = (ii + 1 < T) ? near + span * ga.lin[ii + 1] : 0.0f;
             const float delta = (ii + 1 < T) ? z_next - zv : sample_dist;
             const float alpha = valid ? 1.0f - expf(((-delta) * na.density_scale) * sigma) : 0.0f;
@@ -1293,7 +1912,7 @@ __global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetAr
             const bool masked = valid && w > 1e-4f;
             float cr = 0, cg = 0, cb = 0;
             if (__ballot(masked && lane < 16) != 0ull) {
-                net_color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
+                NET::color(na, Wlds, lane, dx, dy, dz, s16, cr, cg, cb);
                 if (!masked) { cr = 0; cg = 0; cb = 0; }
             }
             if (lane < 16 && valid) {
@@ -1342,6 +1961,7 @@ __global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetAr
         __builtin_amdgcn_wave_barrier();
         // ---------------- pass 2: network backward per tile ----------------
         float a_o[3] = {0, 0, 0}, a_d[3] = {0, 0, 0};
+        const float G[3] = {Gi0, Gi1, Gi2};
         for (uint32_t i0 = 0; i0 < t_end; i0 += 16) {
             const uint32_t idx = i0 + c;
             const bool valid = idx < t_end;
@@ -1350,133 +1970,24 @@ __global__ void __launch_bounds__(kGradWaves * 64, 1) k_render_uniform_bwd(NetAr
             const float ux = ox + dx * zv, uy = oy + dy * zv, uz = oz + dz * zv;          // before the clip (for its derivative)
             const float x = clampf(ux, ga.aabb_lo, ga.aabb_hi), y = clampf(uy, ga.aabb_lo, ga.aabb_hi), z = clampf(uz, ga.aabb_lo, ga.aabb_hi);
             // ---- forward recompute, keeping corners and activations
-            bool oob;
-            uint32_t raw[4][8];
-            float fr[4][3], scl[4];
-            fused_gather<MODE>(na, *lt, q, x, y, z, raw, fr, oob);
-#pragma unroll
-            for (int i = 0; i < 4; i++) scl[i] = lt->scale[q + 4 * i];
-            half8 feat;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                _Float16 f0, f1;
-                corners_to_feature(fr[i], raw[i], oob, f0, f1);
-                feat[2 * i] = f0; feat[2 * i + 1] = f1;
-            }
-            half8 hs[3][2], hs_last[2];                            // sigma net: post-activations of the input layer and of each hidden layer
-            mlp_in(Ws, lane, feat, hs[0]);                         // (indices stay compile-time constants: register arrays)
-            hs_last[0] = hs[0][0]; hs_last[1] = hs[0][1];
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-                if ((uint32_t)k < na.sig_mm) {
-                    mlp_hidden(Ws + 256 + k * 512, lane, hs_last);
-                    hs[k + 1][0] = hs_last[0]; hs[k + 1][1] = hs_last[1];
-                }
-            const f32x4 so = mlp_out(Ws + 256 + na.sig_mm * 512, lane, hs_last);
-            _Float16 s16[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) s16[r] = (_Float16)so[r];
+            typename NET::Tape tape;
+            typename NET::geo_t s16[4];
+            NET::density_tape(na, Wlds, *lt, lane, x, y, z, tape, s16);
             const float wscale = valid ? s_g[ii] : 0.0f;            // w [w > 1e-4]: zero when the reference does not evaluate the colour
             const float dsig = valid ? s_sig[ii] : 0.0f;
             f32x4 gso = {0, 0, 0, 0};                               // dL/d(sigma-net outputs 4q .. 4q+3) of sample c
             float gdir[3] = {0, 0, 0};
             if (__ballot(wscale != 0.0f && lane < 16) != 0ull) {
-                // ---- colour net forward with kept activations
-                float sh[4];
-                sh4_quarter(q, dx, dy, dz, sh);
-                half8 cin;
-#pragma unroll
-                for (int r = 0; r < 4; r++) { cin[r] = (_Float16)sh[r]; cin[4 + r] = s16[r]; }
-                if (q == 0) cin[4] = (_Float16)0;
-                half8 hc[4][2], hc_last[2];
-                mlp_in(Wc, lane, cin, hc[0]);
-                hc_last[0] = hc[0][0]; hc_last[1] = hc[0][1];
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    if ((uint32_t)k < na.col_mm) {
-                        mlp_hidden(Wc + 256 + k * 512, lane, hc_last);
-                        hc[k + 1][0] = hc_last[0]; hc[k + 1][1] = hc_last[1];
-                    }
-                const f32x4 co = mlp_out(Wc + 256 + na.col_mm * 512, lane, hc_last);
-                // ---- backward: sigmoid (on the fp16-rounded value, as torch.sigmoid's backward does), out layer, hidden, in
                 const float wsc = __shfl(wscale, c, 64);             // lanes 0..15 hold the per-sample values: broadcast to the sample's 4 lanes
-                half8 gco = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (q == 0) {
-                    const float G[3] = {Gi0, Gi1, Gi2};
-#pragma unroll
-                    for (int k3 = 0; k3 < 3; k3++) {
-                        const float yv = (float)(_Float16)(1.0f / (1.0f + expf(-(float)(_Float16)co[k3])));
-                        gco[k3] = (_Float16)(G[k3] * wsc * (yv * (1.0f - yv)));
-                    }
-                }
-                f32x4 acc[4];
-                half8 gc[2];
-                mlp_out_bwd(Bc, lane, gco, acc);
-                relu_mask_pack(acc, hc_last, gc);
-#pragma unroll
-                for (int l = 2; l >= 0; l--)                        // through hidden matmul l (input activations hc[l]), last first
-                    if ((uint32_t)l < na.col_mm) {
-                        mlp_hidden_bwd(Bc + 256 + (na.col_mm - 1 - l) * 512, lane, gc, acc);
-                        relu_mask_pack(acc, hc[l], gc);
-                    }
-                f32x4 gin[2];
-                mlp_in_bwd(Bc + 256 + na.col_mm * 512, lane, gc, gin);
-                // accumulator (ob, r) = gradient of colour input perm_color(q, 4 ob + r): ob 0 -> SH 4q + r, ob 1 -> sigma-net output 4q + r
-                const float gsh[4] = {(float)(_Float16)gin[0][0], (float)(_Float16)gin[0][1], (float)(_Float16)gin[0][2], (float)(_Float16)gin[0][3]};
-                sh4_quarter_vjp(q, dx, dy, dz, gsh, gdir);
-#pragma unroll
-                for (int r = 0; r < 4; r++) gso[r] = (float)(_Float16)gin[1][r];
-                if (q == 0) gso[0] = 0.0f;                          // that slot was the zero pad, not sigma
+                NET::color_vjp(na, Wlds, Wb, lane, dx, dy, dz, s16, wsc, G, gdir, gso);
             }
             // ---- sigma: trunc_exp backward (activation.py:12-17) on output 0
             {
                 const float ds = __shfl(dsig, c, 64);
                 if (q == 0) gso[0] = ds * expf(fminf(15.0f, fmaxf(-15.0f, (float)s16[0])));
             }
-            half8 gs_out = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 4; r++) gs_out[r] = (_Float16)gso[r];
-            f32x4 acc[4];
-            half8 gsn[2];
-            mlp_out_bwd(Bs, lane, gs_out, acc);
-            relu_mask_pack(acc, hs_last, gsn);
-#pragma unroll
-            for (int l = 1; l >= 0; l--)
-                if ((uint32_t)l < na.sig_mm) {
-                    mlp_hidden_bwd(Bs + 256 + (na.sig_mm - 1 - l) * 512, lane, gsn, acc);
-                    relu_mask_pack(acc, hs[l], gsn);
-                }
-            f32x4 gfe[2];
-            mlp_in_bwd(Bs + 256 + na.sig_mm * 512, lane, gsn, gfe);
-            // accumulator (ob, r) = gradient of feature perm_grid(q, 4 ob + r) = level q + 4 (2 ob + (r >> 1)), channel r & 1
-            float gx[3] = {0, 0, 0};
-            if (!oob) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float g0 = (float)(_Float16)gfe[i >> 1][2 * (i & 1)], g1 = (float)(_Float16)gfe[i >> 1][2 * (i & 1) + 1];
-#pragma unroll
-                    for (int gd = 0; gd < 3; gd++) {              // gridencoder.cu:177-222: d feature / d u_gd = scale * sum_4 w (right - left)
-                        float d0 = 0.0f, d1 = 0.0f;
-#pragma unroll
-                        for (int k4 = 0; k4 < 4; k4++) {
-                            float w = scl[i];
-                            int left = 0;
-#pragma unroll
-                            for (int nd = 0; nd < 2; nd++) {
-                                const int d = (nd >= gd) ? (nd + 1) : nd;
-                                const int bit = (k4 >> nd) & 1;
-                                w *= bit ? fr[i][d] : 1 - fr[i][d];
-                                left |= bit << d;
-                            }
-                            const int right = left | (1 << gd);
-                            const uint32_t rl = raw[i][left], rr = raw[i][right];
-                            d0 = fmaf(w, (float)__builtin_bit_cast(_Float16, (uint16_t)(rr & 0xffffu)) - (float)__builtin_bit_cast(_Float16, (uint16_t)(rl & 0xffffu)), d0);
-                            d1 = fmaf(w, (float)__builtin_bit_cast(_Float16, (uint16_t)(rr >> 16)) - (float)__builtin_bit_cast(_Float16, (uint16_t)(rl >> 16)), d1);
-                        }
-                        gx[gd] = fmaf(g0, d0, fmaf(g1, d1, gx[gd]));
-                    }
-                }
-            }
+            float gx[3];
+            NET::density_vjp(na, Wb, lane, tape, gso, gx);
             // reduce the four level groups of a sample, then x = clip(o + d z): (x + bound) / (2 bound) upstream
 #pragma unroll
             for (int d = 0; d < 3; d++) {
@@ -1616,7 +2127,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
     const uint32_t n_chunks = (n_alive + 63) / 64;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t w_bytes = (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2;
+    const size_t w_bytes = net_w_bytes(na);
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
     WaveSlab* slabs = reinterpret_cast<WaveSlab*>(smem + w_bytes + sizeof(LevelTab));
@@ -2330,6 +2841,8 @@ static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* p
     na.density_scale = m->density_scale;
     na.align_corners = m->align_corners;
     na.dbg_shrink = dbg.shrink();
+    NGP_REQUIRE(m->precision == NGP_PREC_F16 || m->precision == NGP_PREC_F32, "ngp_model: unknown precision %u", m->precision);
+    na.f32 = m->precision == NGP_PREC_F32 ? 1u : 0u;
     na.cells = nullptr;
     na.cell_steps = 0;
     for (int l = 0; l < 16; l++) na.cell_off[l] = 0;
@@ -2337,6 +2850,7 @@ static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* p
         NGP_REQUIRE(m->cell_levels % 4 == 0 && m->cell_levels <= 16, "ngp_model: cell_levels must be 0, 4, 8, 12 or 16 (got %u)", m->cell_levels);
         NGP_REQUIRE(cell_records(lv, m->cell_levels, na.cell_off) != 0, "ngp_model: the cell tables of %u levels exceed 2^32 records", m->cell_levels);
         NGP_REQUIRE(((uintptr_t)m->cell_tables & 15) == 0, "ngp_model: cell_tables must be 16-byte aligned");
+        NGP_REQUIRE(!na.f32, "ngp_model: per-cell records exist for the fp16 table only");
         if (m->cell_levels == 12 && !needs_generic(lv)) {   // the kernels are specialised for exactly 12 expanded levels
             na.cells = reinterpret_cast<const uint4*>(m->cell_tables);
             na.cell_steps = 3;
@@ -2345,7 +2859,22 @@ static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* p
     return NGP_OK;
 }
 
-static size_t weights_bytes(const NetArgs& na) { return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2; }
+static size_t weights_bytes(const NetArgs& na) { return net_w_bytes(na); }
+
+// kernel variant of a model: 0 / 1 / 2 = fp16 (AND-reduced indices, generic modulo, per-cell records), 3 / 4 = fp32 (AND, generic)
+static int net_variant(const NetArgs& na, const GridLevels& lv) {
+    const bool gen = needs_generic(lv);
+    return na.f32 ? (gen ? 4 : 3) : (gen ? 1 : (na.cells ? 2 : 0));
+}
+// runs STMT with NET bound to the policy class of `variant`
+#define NGP_WITH_NET(variant, ...)                                           \
+    switch (variant) {                                                       \
+        case 0: { using NET = NetF16<0>; __VA_ARGS__; } break;               \
+        case 1: { using NET = NetF16<1>; __VA_ARGS__; } break;               \
+        case 2: { using NET = NetF16<2>; __VA_ARGS__; } break;               \
+        case 3: { using NET = NetF32<0>; __VA_ARGS__; } break;               \
+        default: { using NET = NetF32<1>; __VA_ARGS__; } break;              \
+    }
 
 extern "C" {
 
@@ -2448,6 +2977,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const _Float16* packed = model && model->packed_weights ? (const _Float16*)model->packed_weights : ctx->packed;
     int rc = fill_net(model, dbg, packed, na, lv);
     if (rc) return rc;
+    NGP_REQUIRE(!na.f32, "render_rays: the occupancy-grid loop is built for the fp16 network (ngp_model::precision == NGP_PREC_F16)");
     if (!model->packed_weights) {
         const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
         k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
@@ -2662,6 +3192,11 @@ int ngp_debug_fused_features(const ngp_model* model, const float* xyzs, uint32_t
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
     uint32_t blocks = div_up(div_up(M, 16), 4);
     if (blocks > 1024) blocks = 1024;
+    if (na.f32) {   // `features` is float [M, 32] then; one arithmetic only (the operator's)
+        if (needs_generic(lv)) k_debug_features32<1><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, (float*)features);
+        else k_debug_features32<0><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, (float*)features);
+        return check_launch("debug_fused_features");
+    }
     const int mode = needs_generic(lv) ? 1 : (na.cells ? 2 : 0);
 #define NGP_DBG_FEAT(MODE_, HA_)                                                                              \
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_debug_features<MODE_, HA_>), 96 * 1024);               \
@@ -2689,7 +3224,7 @@ int ngp_render_ctx_set_debug(ngp_render_ctx* ctx, int enable, int flags, unsigne
     return NGP_OK;
 }
 
-size_t ngp_packed_weights_bytes(void) { return (size_t)(sig_halfs(2) + sig_halfs(3)) * 2; }
+size_t ngp_packed_weights_bytes(void) { return (size_t)(sig_halfs(2) + sig_halfs(3)) * 4; }   // (sized for the fp32 form; fp16 uses half of it)
 
 int ngp_pack_weights(const ngp_model* model, void* out, ngp_stream_t stream) {
     NGP_REQUIRE(model && model->sigma_weights && model->color_weights && out, "pack_weights: null pointer");
@@ -2697,9 +3232,14 @@ int ngp_pack_weights(const ngp_model* model, void* out, ngp_stream_t stream) {
                 model->sigma_hidden_mm, model->color_hidden_mm);
     NGP_REQUIRE(((uintptr_t)out & 15) == 0, "pack_weights: the buffer must be 16-byte aligned");
     const uint32_t n_packed = sig_halfs(model->sigma_hidden_mm) + sig_halfs(model->color_hidden_mm);
-    k_pack_weights<<<div_up(n_packed, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)model->sigma_weights, model->sigma_hidden_mm,
-                                                                           (const _Float16*)model->color_weights, model->color_hidden_mm,
-                                                                           (_Float16*)out);
+    if (model->precision == NGP_PREC_F32)
+        k_pack_weights_f32<<<div_up(n_packed, 256), 256, 0, (hipStream_t)stream>>>((const float*)model->sigma_weights, model->sigma_hidden_mm,
+                                                                                   (const float*)model->color_weights, model->color_hidden_mm,
+                                                                                   (float*)out);
+    else
+        k_pack_weights<<<div_up(n_packed, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)model->sigma_weights, model->sigma_hidden_mm,
+                                                                               (const _Float16*)model->color_weights, model->color_hidden_mm,
+                                                                               (_Float16*)out);
     return check_launch("pack_weights");
 }
 
@@ -2716,50 +3256,38 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     NGP_REQUIRE(model && model->packed_weights, "render_uniform: model->packed_weights is NULL (ngp_pack_weights fills it)");
     NetArgs na;
     GridLevels lv;
-    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
+    const DebugState dbg = debug_snapshot(nullptr);
+    int rc = fill_net(model, dbg, (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform<0>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform<1>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform<2>), 96 * 1024);
+    NGP_REQUIRE(lds <= 96 * 1024, "render_uniform: the packed weights need %zu bytes of LDS", lds);
+    const int variant = net_variant(na, lv);
     uint32_t blocks = div_up(N, 4);
     if (blocks > 1024) blocks = 1024;   // 4 workgroups of 4 waves per CU; each wave strides over rays
     ProfScope prof("render_uniform", s, (double)N * T);
     // tiles across sixteen neighbouring rays (twice the per-sample rate) once there are enough groups of sixteen to occupy the chip;
     // a pose-estimator batch (1024 scattered pixels, every ray dumped) keeps one ray per wave
-    const bool per_ray = getenv("NGP_UNIFORM_PER_RAY") != nullptr;            // diagnostics (read per call): tiles along one ray for every size
+    const bool per_ray = getenv("NGP_UNIFORM_PER_RAY") != nullptr;            // diagnostics (read per call: tests switch it): tiles along one ray for every size
     const uint32_t x16_min = getenv("NGP_UNIFORM_X16_MIN") ? (uint32_t)atoi(getenv("NGP_UNIFORM_X16_MIN")) : kUniformX16MinRays;
     if (!per_ray && N >= x16_min) {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<0>), 96 * 1024);
-        ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<1>), 96 * 1024);
-        ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<2>), 96 * 1024);
         // frame_width (scheduling hint, results do not depend on it): the rays are the pixels of row-major frames this wide -> a
         // group is a 4x4-pixel block instead of a 1x16 strip (its sixteen rays are closer together and end at more similar depths)
-        unsigned long long* dbg_stamps = debug_snapshot(nullptr).stamps;
         uint32_t fw = frame_width;
         if (fw && (fw % 4 != 0 || N % (4 * fw) != 0)) fw = 0;
         uint32_t gb = div_up(div_up(N, 16), 4);
         if (gb > 1024) gb = 1024;
-        if (needs_generic(lv))
-            k_render_uniform_x16<1><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps, nullptr, nullptr);
-        else if (na.cells)
-            k_render_uniform_x16<2><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps, nullptr, nullptr);
-        else
-            k_render_uniform_x16<0><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                         dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg_stamps, nullptr, nullptr);
+        NGP_WITH_NET(variant, {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<NET>), 96 * 1024);
+            k_render_uniform_x16<NET><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                           dump_begin, sigmas, rgbs, -model->bound, model->bound, fw, dbg.stamps, nullptr, nullptr);
+        });
         return check_launch("render_uniform");
     }
-    if (needs_generic(lv))
-        k_render_uniform<1><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                     dump_begin, sigmas, rgbs, -model->bound, model->bound);
-    else if (na.cells)
-        k_render_uniform<2><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                     dump_begin, sigmas, rgbs, -model->bound, model->bound);
-    else
-        k_render_uniform<0><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
-                                                     dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    NGP_WITH_NET(variant, {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform<NET>), 96 * 1024);
+        k_render_uniform<NET><<<blocks, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
+                                                       dump_begin, sigmas, rgbs, -model->bound, model->bound);
+    });
     return check_launch("render_uniform");
 }
 
@@ -2786,6 +3314,7 @@ int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float
     GridLevels lv;
     int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
+    NGP_REQUIRE(!na.f32, "render_upsample: built for the fp16 network (ngp_model::precision == NGP_PREC_F16)");
     const size_t fixed = weights_bytes(na) + sizeof(LevelTab), per_wave = ((size_t)5 * T + (size_t)4 * U) * sizeof(float);
     const size_t budget = 160 * 1024 - 1024;
     NGP_REQUIRE(fixed + per_wave <= budget, "render_upsample: num_steps %u + upsample_steps %u need %zu bytes of LDS per ray, %zu are available", T, U,
@@ -2827,9 +3356,9 @@ int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float
     float* sf = zf + Np * U;
     _Float16* gc = reinterpret_cast<_Float16*>(sf + Np * U);
     _Float16* gf = gc + Np * T * 16;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<0, true>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<1, true>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<2, true>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<NetF16<0>, true>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<NetF16<1>, true>), 96 * 1024);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<NetF16<2>, true>), 96 * 1024);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_composite_merged_x16<0>), 96 * 1024);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_composite_merged_x16<1>), 96 * 1024);
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_composite_merged_x16<2>), 96 * 1024);
@@ -2837,13 +3366,13 @@ int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float
     if (gb > 1024) gb = 1024;
     auto density = [&](uint32_t n, const float* z_in, float* out, _Float16* geo) {
         if (mode == 1)
-            k_render_uniform_x16<1, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
+            k_render_uniform_x16<NetF16<1>, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
                                                                  nullptr, -model->bound, model->bound, fw, nullptr, z_in, geo);
         else if (mode == 2)
-            k_render_uniform_x16<2, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
+            k_render_uniform_x16<NetF16<2>, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
                                                                  nullptr, -model->bound, model->bound, fw, nullptr, z_in, geo);
         else
-            k_render_uniform_x16<0, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
+            k_render_uniform_x16<NetF16<0>, true><<<gb, 256, fixed, s>>>(na, lv, rays_o, rays_d, nears, fars, N, n, lin, nullptr, nullptr, nullptr, nullptr, 0, out,
                                                                  nullptr, -model->bound, model->bound, fw, nullptr, z_in, geo);
     };
     density(T, nullptr, sc, gc);
@@ -2861,17 +3390,38 @@ int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float
     return check_launch("render_upsample");
 }
 
-size_t ngp_packed_weights_bwd_bytes(void) { return (size_t)(bwd_halfs(2) + bwd_halfs(3)) * 2; }
+size_t ngp_packed_weights_bwd_bytes(void) {      // (sized for whichever form is larger)
+    const size_t h = (size_t)(bwd_halfs(2) + bwd_halfs(3)) * 2, f = (size_t)(bwd_floats(2) + bwd_floats(3)) * 4;
+    return h > f ? h : f;
+}
 
 int ngp_pack_weights_bwd(const ngp_model* model, void* out, ngp_stream_t stream) {
     NGP_REQUIRE(model && model->sigma_weights && model->color_weights && out, "pack_weights_bwd: null pointer");
     NGP_REQUIRE(model->sigma_hidden_mm <= 2 && model->color_hidden_mm <= 3, "pack_weights_bwd: at most 2 / 3 hidden matmuls (got %u / %u)",
                 model->sigma_hidden_mm, model->color_hidden_mm);
     NGP_REQUIRE(((uintptr_t)out & 15) == 0, "pack_weights_bwd: the buffer must be 16-byte aligned");
-    const uint32_t n = bwd_halfs(model->sigma_hidden_mm) + bwd_halfs(model->color_hidden_mm);
-    k_pack_weights_bwd<<<div_up(n, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)model->sigma_weights, model->sigma_hidden_mm,
-                                                                        (const _Float16*)model->color_weights, model->color_hidden_mm, (_Float16*)out);
+    if (model->precision == NGP_PREC_F32) {
+        const uint32_t n = bwd_floats(model->sigma_hidden_mm) + bwd_floats(model->color_hidden_mm);
+        k_pack_weights_bwd_f32<<<div_up(n, 256), 256, 0, (hipStream_t)stream>>>((const float*)model->sigma_weights, model->sigma_hidden_mm,
+                                                                                (const float*)model->color_weights, model->color_hidden_mm, (float*)out);
+    } else {
+        const uint32_t n = bwd_halfs(model->sigma_hidden_mm) + bwd_halfs(model->color_hidden_mm);
+        k_pack_weights_bwd<<<div_up(n, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)model->sigma_weights, model->sigma_hidden_mm,
+                                                                            (const _Float16*)model->color_weights, model->color_hidden_mm, (_Float16*)out);
+    }
     return check_launch("pack_weights_bwd");
+}
+
+// the fp32 backward kernels keep at most 1 / 2 hidden layers' activations (NetF32::Tape; nerf/network.py has 0 / 1)
+static bool bwd_shape_ok(const NetArgs& na) { return !na.f32 || (na.sig_mm <= NetF32<0>::kMaxSigMM && na.col_mm <= NetF32<0>::kMaxColMM); }
+
+size_t ngp_render_uniform_backward_lds(const ngp_model* model, uint32_t T) {
+    if (!model) return 0;
+    NetArgs na = {};
+    na.sig_mm = model->sigma_hidden_mm; na.col_mm = model->color_hidden_mm; na.f32 = model->precision == NGP_PREC_F32;
+    if (!bwd_shape_ok(na)) return (size_t)-1;
+    const size_t wb = na.f32 ? NetF32<0>::wb_bytes(na) : NetF16<0>::wb_bytes(na);
+    return net_w_bytes(na) + wb + sizeof(LevelTab) + (size_t)(na.f32 ? 4 : kGradWaves) * 3 * T * 4;
 }
 
 int ngp_render_uniform_backward(const ngp_model* model, const void* packed_weights_bwd, const float* rays_o, const float* rays_d, const float* nears,
@@ -2887,23 +3437,30 @@ int ngp_render_uniform_backward(const ngp_model* model, const void* packed_weigh
     GridLevels lv;
     int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
+    NGP_REQUIRE(bwd_shape_ok(na), "render_uniform_backward: the fp32 form supports at most 1 / 2 hidden matmuls (got %u / %u)", na.sig_mm, na.col_mm);
     GradArgs ga = {rays_o, rays_d, nears, fars, lin, grad_image, grad_depth, grad_weights_sum, grad_aggregated_density, grad_rays_o, grad_rays_d,
-                   (const _Float16*)packed_weights_bwd, N, T, -model->bound, model->bound, g_grad_dump};
-    const size_t lds = weights_bytes(na) + (size_t)(bwd_halfs(na.sig_mm) + bwd_halfs(na.col_mm)) * 2 + sizeof(LevelTab) + (size_t)kGradWaves * 3 * T * 4;
+                   packed_weights_bwd, N, T, -model->bound, model->bound, g_grad_dump};
+    const size_t lds = ngp_render_uniform_backward_lds(model, T);
     NGP_REQUIRE(lds <= 160 * 1024, "render_uniform_backward: LDS budget exceeded (%zu bytes: at most %u samples per ray with this network)", lds, T);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<0>), 160 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<1>), 160 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<2>), 160 * 1024);
-    uint32_t blocks = div_up(N, kGradWaves);
-    if (blocks > 512) blocks = 512;
     ProfScope prof("render_uniform_backward", s, (double)N * T);
-    if (needs_generic(lv)) k_render_uniform_bwd<1><<<blocks, kGradWaves * 64, lds, s>>>(na, lv, ga);
-    else if (na.cells) k_render_uniform_bwd<2><<<blocks, kGradWaves * 64, lds, s>>>(na, lv, ga);
-    else k_render_uniform_bwd<0><<<blocks, kGradWaves * 64, lds, s>>>(na, lv, ga);
+    // four rays per workgroup: always in fp32; in fp16 while that still gives every CU at most two rounds of work
+    static const int force_gw = getenv("NGP_GRAD_WAVES") ? atoi(getenv("NGP_GRAD_WAVES")) : 0;     // diagnostics
+    const bool four = na.f32 || (force_gw ? force_gw == 4 : N <= 2048);
+    uint32_t blocks = div_up(N, four ? 4 : kGradWaves);
+    if (blocks > 512) blocks = 512;
+    NGP_WITH_NET(net_variant(na, lv), {
+        if (four) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<NET, 4>), 160 * 1024);
+            k_render_uniform_bwd<NET, 4><<<blocks, 4 * 64, lds, s>>>(na, lv, ga);
+        } else {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_bwd<NET, kGradWaves>), 160 * 1024);
+            k_render_uniform_bwd<NET, kGradWaves><<<blocks, kGradWaves * 64, lds, s>>>(na, lv, ga);
+        }
+    });
     return check_launch("render_uniform_backward");
 }
 
-int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, float* sigmas, ngp_stream_t stream) {
+int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, ngp_stream_t stream) {
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(xyzs && sigmas, "network_density: null pointer");
     NGP_REQUIRE(model && model->packed_weights, "network_density: model->packed_weights is NULL (ngp_pack_weights fills it)");
@@ -2913,16 +3470,39 @@ int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, f
     int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<0>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<1>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<2>), 96 * 1024);
+    NGP_REQUIRE(lds <= 96 * 1024, "network_density: the packed weights need %zu bytes of LDS", lds);
     uint32_t blocks = div_up(div_up(M, 16), 4);
     if (blocks > 1024) blocks = 1024;
     ProfScope prof("network_density", s, M);
-    if (needs_generic(lv)) k_network_density<1><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, sigmas);
-    else if (na.cells) k_network_density<2><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, sigmas);
-    else k_network_density<0><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, sigmas);
+    NGP_WITH_NET(net_variant(na, lv), {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<NET>), 96 * 1024);
+        k_network_density<NET><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, sigmas, geo_feat);
+    });
     return check_launch("network_density");
+}
+
+int ngp_network_density_backward(const ngp_model* model, const void* packed_weights_bwd, const float* xyzs, uint32_t M, const float* grad_sigmas,
+                                 const float* grad_geo_feat, float* grad_xyzs, ngp_stream_t stream) {
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(xyzs && grad_xyzs && (grad_sigmas || grad_geo_feat), "network_density_backward: null pointer");
+    NGP_REQUIRE(model && model->packed_weights && packed_weights_bwd, "network_density_backward: packed weights missing (ngp_pack_weights / ngp_pack_weights_bwd)");
+    hipStream_t s = (hipStream_t)stream;
+    NetArgs na;
+    GridLevels lv;
+    int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
+    if (rc) return rc;
+    NGP_REQUIRE(bwd_shape_ok(na), "network_density_backward: the fp32 form supports at most 1 hidden matmul in the sigma net (got %u)", na.sig_mm);
+    const size_t ws = na.f32 ? (size_t)bwd_floats(na.sig_mm) * 4 : (size_t)bwd_halfs(na.sig_mm) * 2;
+    const size_t lds = weights_bytes(na) + ws + sizeof(LevelTab);
+    NGP_REQUIRE(lds <= 160 * 1024, "network_density_backward: LDS budget exceeded (%zu bytes)", lds);
+    uint32_t blocks = div_up(div_up(M, 16), 4);
+    if (blocks > 1024) blocks = 1024;
+    ProfScope prof("network_density_backward", s, M);
+    NGP_WITH_NET(net_variant(na, lv), {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density_bwd<NET>), 160 * 1024);
+        k_network_density_bwd<NET><<<blocks, 256, lds, s>>>(na, lv, (const char*)packed_weights_bwd, xyzs, M, grad_sigmas, grad_geo_feat, grad_xyzs);
+    });
+    return check_launch("network_density_backward");
 }
 
 int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* dirs, uint32_t M, float* sigmas, float* rgbs,
@@ -2938,16 +3518,15 @@ int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* 
     int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<0>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<1>), 96 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<2>), 96 * 1024);
+    NGP_REQUIRE(lds <= 96 * 1024, "network_forward: the packed weights need %zu bytes of LDS", lds);
     const uint32_t n_tiles = div_up(M, 16);
     uint32_t blocks = div_up(n_tiles, 4);
     if (blocks > 1024) blocks = 1024;
     ProfScope prof("network_forward", s, M);
-    if (needs_generic(lv)) k_network_forward<1><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
-    else if (na.cells) k_network_forward<2><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
-    else k_network_forward<0><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    NGP_WITH_NET(net_variant(na, lv), {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<NET>), 96 * 1024);
+        k_network_forward<NET><<<blocks, 256, lds, s>>>(na, lv, xyzs, dirs, M, sigmas, rgbs);
+    });
     return check_launch("network_forward");
 }
 

@@ -52,6 +52,7 @@ class NeRFNetwork(NeRFRenderer):
         else:
             self.bg_net = None
         self._fused_cache = None
+        self._fused_cache32 = None
 
     def forward(self, x, d):
         """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N], color [N,3]"""
@@ -62,6 +63,21 @@ class NeRFNetwork(NeRFRenderer):
         return sigma, torch.sigmoid(h)
 
     def density(self, x):
+        """x [..., 3] -> {'sigma': [...], 'geo_feat': [..., 15]} (nerf/network.py:126-143).  With the map frozen (or outside
+        autograd) and no autocast -- how validate.py's density_fn reaches it, 250 planner steps per simulator step with d sigma / d x
+        (nav/quad_plot.py:223-249) -- one fused launch forward and one backward (_fused.NetworkDensity); otherwise the operators."""
+        if (self.fused and x.is_cuda and not torch.is_autocast_enabled("cuda") and x.shape[-1] == 3 and x.numel() > 0
+                and (not torch.is_grad_enabled() or self._map_is_frozen())):
+            fm = self.fused_model()
+            if fm is not None and fm.f32:
+                from .._fused import NetworkDensity
+                sigma, geo = NetworkDensity.apply(fm, x.reshape(-1, 3))
+                return {"sigma": sigma.view(x.shape[:-1]), "geo_feat": geo.view(*x.shape[:-1], 15)}
+        return self._density_operators(x)
+
+    def _density_operators(self, x):
+        """density() operator by operator (grid_encode -> nn.Linear chain -> trunc_exp): what trains, and what the density-grid
+        maintenance queries (renderer._grid_sigmas)"""
         h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
@@ -96,11 +112,20 @@ class NeRFNetwork(NeRFRenderer):
         return params
 
     def fused_model(self):
-        """fp16 (autocast) eval rendering through ngp_render_rays; None when the configuration is not the fused shape."""
+        """the network as the fused kernels take it, in the precision the reference would evaluate it in HERE: fp16 under autocast
+        (table cast by gridencoder/grid.py:36-39, nn.Linear autocast to half), fp32 outside it (validate.py's rollout);
+        None when the configuration is not the fused shape."""
         from .. import _fused
-        if self.bg_radius > 0 or not torch.is_autocast_enabled("cuda"):
+        if self.bg_radius > 0:
+            return None
+        f32 = not torch.is_autocast_enabled("cuda")
+        if f32 and (self.encoder.embeddings.dtype != torch.float32 or len(self.sigma_net) > 3 or len(self.color_net) > 4):
             return None
         with _fused.CACHE_LOCK:      # frames may be rendered from several host threads (pipeline.py): build the snapshot once
+            if f32:
+                if self._fused_cache32 is None or not self._fused_cache32.valid_for(self):
+                    self._fused_cache32 = _fused.FusedModel.from_linear_network(self, f32=True)
+                return self._fused_cache32
             if self._fused_cache is None or not self._fused_cache.valid_for(self):
                 self._fused_cache = _fused.FusedModel.from_linear_network(self)
             return self._fused_cache

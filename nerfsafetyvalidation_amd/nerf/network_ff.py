@@ -71,7 +71,10 @@ class NeRFNetwork(NeRFRenderer):
 
     def fused_model(self):
         from .. import _fused
-        if self.bg_radius > 0:
+        # Only under autocast: outside it the reference's FFMLP gets fp32 tensors (custom_fwd casts only under autocast, ffmlp.py:18)
+        # and raises at CHECK_IS_HALF (ffmlp.cu:636-642) -- `validate.py --ff` (fp16 = False, validate.py:120-123) never rendered a
+        # frame.  The operators below raise the same way; the fused path must not render from the fp16 table copy instead.
+        if self.bg_radius > 0 or not torch.is_autocast_enabled("cuda"):
             return None
         with _fused.CACHE_LOCK:      # frames may be rendered from several host threads (pipeline.py): build the snapshot once
             if self._fused_cache is None or not self._fused_cache.valid_for(self):

@@ -104,6 +104,7 @@ class NeRFRenderer(nn.Module):
         from ..gridencoder.grid import invalidate_derived
         with _fused.CACHE_LOCK:
             self._fused_cache = None
+            self._fused_cache32 = None
         for name in ("encoder", "encoder_bg"):          # the grid encoders' fp16 copies / per-cell records follow the same rule
             enc = getattr(self, name, None)
             if enc is not None and hasattr(enc, "embeddings"):
@@ -246,7 +247,7 @@ class NeRFRenderer(nn.Module):
             out["weights_sum"] = acc
         else:
             fm = self.fused_model() if self.fused and not torch.is_grad_enabled() else None
-            if fm is not None:
+            if fm is not None and not fm.f32:      # (the fused occupancy-grid loop exists for the fp16 network; fp32 takes the operators)
                 acc, depth, image, sigmas, rgbs = fm.render(self, origins, directions, nears, fars, dt_gamma, max_steps, perturb,
                                                             want_last=self.return_last_tensors, frame_width=kwargs.get("frame_width", 0))
                 self.last_render_stats = fm.last_stats
@@ -284,7 +285,8 @@ class NeRFRenderer(nn.Module):
             fm = self.fused_model()
         if fm is not None:
             return fm.network_density(points)
-        return self.density(points)["sigma"].reshape(-1).detach().float().contiguous()
+        density = getattr(self, "_density_operators", self.density)     # (fp32: the operators' own arithmetic, not the fused fp32 kernel's summation order)
+        return density(points)["sigma"].reshape(-1).detach().float().contiguous()
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):

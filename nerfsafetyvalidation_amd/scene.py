@@ -142,8 +142,9 @@ class StonehengeScene:
     def bitfield(self):
         return packbits_np(self.grid, 0.01)
 
-    def build_model(self, device, backbone="ff", cuda_ray=True, table_seed=0):
-        """NeRFNetwork (FFMLP backbone by default) with the synthetic table, weights and occupancy, in eval mode."""
+    def build_model(self, device, backbone="ff", cuda_ray=True, table_seed=0, fp16_table=True):
+        """NeRFNetwork (FFMLP backbone by default) with the synthetic table, weights and occupancy, in eval mode.
+        fp16_table=False keeps the table's full fp32 draws (NOT representable in fp16: what an fp32-trained checkpoint holds)."""
         if backbone == "ff":
             from .nerf.network_ff import NeRFNetwork
         else:
@@ -153,7 +154,7 @@ class StonehengeScene:
                             min_near=self.min_near, density_thresh=0.01, bg_radius=-1)
         g = torch.Generator().manual_seed(table_seed)
         emb = torch.rand(model.encoder.embeddings.shape, generator=g) - 0.5
-        model.encoder.embeddings.data.copy_(emb.half().float())
+        model.encoder.embeddings.data.copy_(emb.half().float() if fp16_table else emb)
         if cuda_ray:
             model.density_grid.copy_(torch.from_numpy(self.grid))
             model.density_bitfield.copy_(torch.from_numpy(self.bitfield()))

@@ -51,8 +51,14 @@ def test_ctypes_layer_binds_every_symbol():
     assert lib.ngp_grid_encode_backward_workspace(1 << 20, 3, 2, 16, _lib.NGP_F16) > 0
     assert lib.ngp_grid_encode_backward_workspace(1 << 20, 3, 2, 16, _lib.NGP_F32) == 0
     assert lib.ngp_grid_encode_backward_workspace(4096, 3, 2, 16, _lib.NGP_F16) == 0
-    assert lib.ngp_packed_weights_bytes() == 2 * ((2048 + 2 * 4096 + 1024) + (2048 + 3 * 4096 + 1024))
-    assert ctypes.sizeof(_lib.ModelStruct) == 120 and ctypes.sizeof(_lib.RenderStats) == 40
+    assert lib.ngp_packed_weights_bytes() == 4 * ((2048 + 2 * 4096 + 1024) + (2048 + 3 * 4096 + 1024))    # sized for the fp32 form
+    assert ctypes.sizeof(_lib.ModelStruct) == 128 and ctypes.sizeof(_lib.RenderStats) == 40
+    # LDS budget of the fused backward of `run` (host arithmetic): nerf/network.py's shapes in fp32 fit 512 samples per ray
+    m = _lib.ModelStruct()
+    m.sigma_hidden_mm, m.color_hidden_mm, m.precision = 0, 1, _lib.NGP_PREC_F32
+    assert 0 < lib.ngp_render_uniform_backward_lds(ctypes.byref(m), 512) <= 160 * 1024
+    m.sigma_hidden_mm, m.color_hidden_mm, m.precision = 1, 2, _lib.NGP_PREC_F16
+    assert 0 < lib.ngp_render_uniform_backward_lds(ctypes.byref(m), 512) <= 160 * 1024
 
 
 def test_product_never_imports_the_oracle():

@@ -1,0 +1,307 @@
+"""The fp32 fused path (ngp_model::precision == NGP_PREC_F32): what validate.py's rollout evaluates -- render_fn / density_fn are
+called outside any autocast context (validate.py:288-291), so the reference interpolates the fp32 table (gridencoder/grid.py:36-39)
+and runs nerf/network.py's nn.Linear layers in fp32.  North-star tolerance: 1e-4 on RGB / sigma against the CPU oracle
+(oracle_run + OracleLinearNetwork) and against the reference-driven fixtures; hash-grid features bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import OracleLinearNetwork, oracle_grid_encode, oracle_run, pinhole_rays
+from helpers import encoder_input  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _scene(H, W):
+    from nerfsafetyvalidation_amd.scene import StonehengeScene
+    return StonehengeScene(H=H, W=W, bound=2)
+
+
+def _linear_model(sc, device, fp16_table=False):
+    """nerf/network.py backbone, cuda_ray off (what validate.py -O builds), table with full fp32 draws"""
+    return sc.build_model(device, backbone="linear", cuda_ray=False, fp16_table=fp16_table)
+
+
+def _oracle_net(model):
+    enc = model.encoder
+    return OracleLinearNetwork(enc.embeddings.detach().cpu().numpy(), enc.offsets.cpu().numpy().astype(np.int32), enc.per_level_scale,
+                               [l.weight.detach().cpu().numpy() for l in model.sigma_net],
+                               [l.weight.detach().cpu().numpy() for l in model.color_net], model.bound)
+
+
+def test_table_is_not_fp16_representable(device):
+    m = _linear_model(_scene(16, 16), device)
+    e = m.encoder.embeddings.detach()
+    assert (e.half().float() != e).float().mean() > 0.9
+
+
+def test_fused_features_fp32_bit_exact(device):
+    """the fused kernels' fp32 gather + interpolation against the grid_encode operator and the oracle (gridencoder.cu:139-175 as an
+    fmaf chain over the corners): the 32 features bit for bit, in range, on cell corners and out of range"""
+    from nerfsafetyvalidation_amd import _lib
+    m = _linear_model(_scene(16, 16), device)
+    fm = m.fused_model()
+    assert fm is not None and fm.f32
+    rng = np.random.default_rng(0)
+    x = (rng.random((20000, 3), dtype=np.float32) * 2 - 1) * np.float32(m.bound)
+    x[:64] = np.float32(m.bound) * rng.choice(np.array([-1, 0, 0.5, 1], np.float32), (64, 3))   # faces, centre, corners
+    x[64:96] *= np.float32(1.01)                                                                     # some out of range
+    xt = torch.from_numpy(x).to(device)
+    fm._ensure_packed()
+    feats = torch.empty(x.shape[0], 32, dtype=torch.float32, device=device)
+    ms = fm._struct(None)
+    _lib.check(_lib.lib().ngp_debug_fused_features(C.byref(ms), _lib.ptr(xt), x.shape[0], 0, _lib.ptr(feats), _lib.stream()), "debug_fused_features")
+    with torch.no_grad():
+        op = m.encoder(xt, bound=m.bound)
+    assert op.dtype == torch.float32
+    assert torch.equal(feats, op)
+    want, _ = oracle_grid_encode(encoder_input(x, m.bound), m.encoder.embeddings.detach().cpu().numpy(), m.encoder.offsets.cpu().numpy().astype(np.int32),
+                                 m.encoder.per_level_scale)
+    assert np.array_equal(feats.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("M", [1, 16, 1000, 65537])
+def test_network_forward_and_density_fp32_vs_oracle(device, M):
+    m = _linear_model(_scene(16, 16), device)
+    fm = m.fused_model()
+    rng = np.random.default_rng(M)
+    x = ((rng.random((M, 3), dtype=np.float32) * 2 - 1) * np.float32(0.9 * m.bound)).astype(np.float32)
+    d = rng.standard_normal((M, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    xt, dt = torch.from_numpy(x).to(device), torch.from_numpy(d).to(device)
+    sg, rgb = fm.network_forward(xt, dt)
+    sg2, geo = fm.network_density(xt, want_geo=True)
+    assert torch.equal(sg, sg2)
+    net = _oracle_net(m)
+    want_s, want_c = net.forward(x, d)
+    _, want_geo = net.density(x)
+    # pre-activations agree to fp32 summation order (observed 2e-6 absolute at |h| ~ 1); sigma = exp(h) relative
+    np.testing.assert_allclose(sg.cpu().numpy(), want_s, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(geo.cpu().numpy(), want_geo, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rgb.cpu().numpy(), want_c, rtol=0, atol=1e-5)
+    # and the operator path of this package (grid_encode + nn.Linear through rocBLAS) agrees the same way
+    with torch.no_grad():
+        m.fused = False
+        op_s, op_c = m(xt, dt)
+        m.fused = True
+    np.testing.assert_allclose(sg.cpu().numpy(), op_s.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(rgb.cpu().numpy(), op_c.cpu().numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("size,stride", [(400, 157), (800, 613)])
+def test_run_fp32_full_frame_vs_oracle(device, size, stride):
+    """BASELINE configs[0] (400x400, nerf/network.py backbone, fp32) and the 800x800 frame of the rollout: the whole frame through the
+    fused fp32 `run` (one launch, tiles across rays), every `stride`-th ray against oracle_run: |dRGB|, |d depth| <= 1e-4, sigma of the
+    dumped last chunk <= 1e-4 relative"""
+    sc = _scene(size, size)
+    m = _linear_model(sc, device)
+    view = 7
+    ro, rd = pinhole_rays(sc.poses[view], sc.intrinsics, size, size)
+    rot, rdt = torch.from_numpy(ro).to(device)[None], torch.from_numpy(rd).to(device)[None]
+    kw = dict(staged=True, bg_color=1, perturb=False, num_steps=512, upsample_steps=0, max_ray_batch=4096)
+    with torch.no_grad():
+        out = m.render(rot, rdt, **kw)
+        assert m._fused_cache32 is not None and m._fused_cache is None            # the fp32 snapshot rendered this
+        out_fw = m.render(rot, rdt, frame_width=size, **kw)
+    for k in ("image", "depth", "aggregated_density"):
+        np.testing.assert_allclose(out_fw[k].cpu().numpy(), out[k].cpu().numpy(), rtol=0, atol=2e-6)   # the hint only regroups rays
+    sel = np.arange(0, size * size, stride)
+    want = oracle_run(_oracle_net(m), ro[sel], rd[sel], sc.bound, sc.density_scale, 512)
+    got_img, got_dep = out["image"][0].cpu().numpy()[sel], out["depth"][0].cpu().numpy()[sel]
+    err = np.abs(got_img - want["image"])
+    hit = np.isfinite(want["depth"])
+    derr = np.abs(got_dep[hit] - want["depth"][hit])
+    agg = np.abs(out["aggregated_density"][0].cpu().numpy()[sel][hit] - want["aggregated_density"][hit]) / (1 + np.abs(want["aggregated_density"][hit]))
+    print(f"{size}x{size}: max |dRGB| {err.max():.2e} mean {err.mean():.2e}; max |d depth| {derr.max():.2e}; rel agg {agg.max():.2e}; {sel.size} rays")
+    assert err.max() <= 1e-4 and derr.max() <= 1e-4 and agg.max() <= 1e-4
+    # F8: rgbs / sigmas of the last ray chunk, against the oracle on a few of its rays
+    last_begin = ((size * size - 1) // 4096) * 4096
+    n_last = size * size - last_begin
+    assert out["sigmas"].shape == (n_last * 512, 1) and out["rgbs"].shape == (n_last, 512, 3)
+    pick = np.arange(last_begin, size * size, 97)
+    wl = oracle_run(_oracle_net(m), ro[pick], rd[pick], sc.bound, sc.density_scale, 512)
+    gs = out["sigmas"].view(n_last, 512).cpu().numpy()[pick - last_begin]
+    np.testing.assert_allclose(gs, wl["sigmas"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["rgbs"].cpu().numpy()[pick - last_begin], wl["rgbs"], rtol=0, atol=1e-4)
+
+
+def test_run_fp32_small_batch_form_and_operator_path(device):
+    """fewer than 65 536 rays take one ray per wave; both forms and the operator chain agree within fp32 summation order"""
+    sc = _scene(96, 96)
+    m = _linear_model(sc, device)
+    ro, rd = pinhole_rays(sc.poses[3], sc.intrinsics, 96, 96)
+    rot, rdt = torch.from_numpy(ro).to(device)[None], torch.from_numpy(rd).to(device)[None]
+    kw = dict(staged=True, bg_color=1, perturb=False, num_steps=256, upsample_steps=0, max_ray_batch=4096)
+    with torch.no_grad():
+        fused = m.render(rot, rdt, **kw)
+        m.fused = False
+        ops = m.render(rot, rdt, **kw)
+        m.fused = True
+    for k, tol in (("image", 2e-5), ("depth", 2e-5)):
+        np.testing.assert_allclose(fused[k].cpu().numpy(), ops[k].cpu().numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(fused["aggregated_density"].cpu().numpy(), ops["aggregated_density"].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert fused["rgbs"].shape == ops["rgbs"].shape and fused["sigmas"].shape == ops["sigmas"].shape
+    np.testing.assert_allclose(fused["sigmas"].cpu().numpy(), ops["sigmas"].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    want = oracle_run(_oracle_net(m), ro[::31], rd[::31], sc.bound, sc.density_scale, 256)
+    assert np.abs(fused["image"][0].cpu().numpy()[::31] - want["image"]).max() <= 1e-4
+
+
+def test_render_run_golden_through_the_fused_fp32_path(device):
+    """the reference's own renderer driven on CPU (render_run.npz, uniform sampling) against the fused fp32 launch: 1e-4"""
+    from test_golden_gpu import _network, _rays, load
+    f = load("render_run.npz")
+    net = _network(f, device, cuda_ray=False)
+    ro, rd = _rays(f, device)
+    with torch.no_grad():
+        out = net.render(ro, rd, staged=True, max_ray_batch=int(f["max_ray_batch"]), bg_color=1, perturb=False, num_steps=48, upsample_steps=0)
+        assert net._fused_cache32 is not None
+        net.fused = False
+        ops = net.render(ro, rd, staged=True, max_ray_batch=int(f["max_ray_batch"]), bg_color=1, perturb=False, num_steps=48, upsample_steps=0)
+    for o in (out, ops):
+        np.testing.assert_allclose(o["image"].cpu().numpy(), f["u0_image"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o["depth"].cpu().numpy(), f["u0_depth"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o["rgbs"].cpu().numpy(), f["u0_rgbs"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o["sigmas"].cpu().numpy(), f["u0_sigmas"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("T", [64, 512])
+def test_fused_fp32_pose_gradient_against_the_operator_path(device, T):
+    """d(image, depth) / d(rays) of `run` with the map frozen: ngp_render_uniform_backward in fp32 against autograd over the fp32
+    operator chain (grid_encode dy_dx -> nn.Linear -> SH -> sampling kernels)"""
+    sc = _scene(32, 32)
+    m = _linear_model(sc, device)
+    m.requires_grad_(False)
+    ro, rd = pinhole_rays(sc.poses[11], sc.intrinsics, 32, 32)
+    rng = np.random.default_rng(T)
+    gi = torch.from_numpy(rng.standard_normal((1, 1024, 3)).astype(np.float32)).to(device)
+    gd = torch.from_numpy(rng.standard_normal((1, 1024)).astype(np.float32)).to(device)
+    grads = {}
+    for fused in (True, False):
+        m.fused = fused
+        o = torch.from_numpy(ro).to(device)[None].requires_grad_(True)
+        d = torch.from_numpy(rd).to(device)[None].requires_grad_(True)
+        out = m.render(o, d, staged=True, bg_color=1, perturb=False, num_steps=T, upsample_steps=0, max_ray_batch=4096)
+        ((out["image"] * gi).sum() + (out["depth"] * gd).sum()).backward()
+        grads[fused] = (o.grad[0].cpu().numpy(), d.grad[0].cpu().numpy(), out["image"].detach().cpu().numpy())
+    m.fused = True
+    np.testing.assert_allclose(grads[True][2], grads[False][2], rtol=0, atol=2e-5)
+    for a, b, name in ((grads[True][0], grads[False][0], "grad_o"), (grads[True][1], grads[False][1], "grad_d")):
+        scale = np.abs(b).max()
+        rel = np.abs(a - b).max() / scale
+        med = np.median(np.abs(a - b) / (np.abs(b) + 1e-3 * scale))
+        print(f"T={T} {name}: max |diff| / max |grad| {rel:.2e}, median relative {med:.2e}")
+        # fp32 everywhere; what differs is summation order (and ReLU units within rounding of zero, rare): observed ~1e-5
+        assert rel < 2e-3 and med < 1e-4
+
+
+def test_render_run_grad_golden_through_the_fused_fp32_path(device):
+    """render_run_grad.npz: d(rendered pixels) / d(pose, rays) through get_rays(inds) -> render -> run as the reference's autograd
+    gives it on CPU (fp32), against the fused fp32 forward + backward with the map frozen"""
+    from test_golden_gpu import _network, _t, load
+    from nerfsafetyvalidation_amd import scene as SC
+    from nerfsafetyvalidation_amd.nerf.utils import get_rays
+    f = load("render_run_grad.npz")
+    net = _network(f, device, cuda_ray=False)
+    net.requires_grad_(False)
+    H, W = int(f["H"]), int(f["W"])
+    pose = _t(SC.orbit_poses()[int(f["view"]):int(f["view"]) + 1].copy(), device).requires_grad_(True)
+    rays = get_rays(pose, SC.intrinsics(H, W), H, W, inds=torch.from_numpy(f["inds"]))
+    ro, rd = rays["rays_o"], rays["rays_d"]
+    ro.retain_grad()
+    rd.retain_grad()
+    out = net.render(ro, rd, staged=True, bg_color=1, perturb=False, num_steps=32, upsample_steps=0)
+    assert "RunUniform" in str(out["depth"].grad_fn.next_functions) or "RunUniform" in type(out["depth"].grad_fn).__name__
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), f["image"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), f["depth"], rtol=0, atol=1e-4)
+    loss = (out["image"] * _t(f["wts"], device)).sum() + (out["depth"] * _t(f["wd"], device)).sum()
+    assert abs(float(loss.detach()) - float(f["loss"])) < 1e-3
+    loss.backward()
+    for got, key in ((ro.grad, "grad_rays_o"), (rd.grad, "grad_rays_d"), (pose.grad, "grad_pose")):
+        want = f[key]
+        err = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        print(f"{key}: max |diff| / max |grad| = {err:.2e}")
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=2e-4 * np.abs(want).max())
+    assert net.encoder.embeddings.grad is None
+
+
+@pytest.mark.parametrize("M", [500, 6000])
+def test_density_with_gradient_fp32(device, M):
+    """the planner's query (nav/quad_plot.py:223-249: density_fn(points) ** 2 ... backward to the points): NeRFNetwork.density under
+    autograd with a frozen map is one fused launch each way; against autograd over the fp32 operators and against the oracle"""
+    sc = _scene(16, 16)
+    m = _linear_model(sc, device)
+    m.requires_grad_(False)
+    rng = np.random.default_rng(M)
+    x = ((rng.random((M, 3), dtype=np.float32) * 2 - 1) * np.float32(0.8 * m.bound)).astype(np.float32)
+    x[:8] *= np.float32(1.3)        # a few outside the box: zero features, zero gradient
+    gs = rng.standard_normal(M).astype(np.float32)
+    res = {}
+    for fused in (True, False):
+        m.fused = fused
+        xt = torch.from_numpy(x).to(device).requires_grad_(True)
+        out = m.density(xt)
+        assert out["sigma"].shape == (M,) and out["geo_feat"].shape == (M, 15)
+        (out["sigma"] * torch.from_numpy(gs).to(device)).sum().backward()
+        res[fused] = (out["sigma"].detach().cpu().numpy(), out["geo_feat"].detach().cpu().numpy(), xt.grad.cpu().numpy())
+    m.fused = True
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=0, atol=2e-5)
+    scale = np.abs(res[False][2]).max()
+    diff = np.abs(res[True][2] - res[False][2])
+    print(f"M={M}: max |d grad| / max |grad| {diff.max() / scale:.2e}")
+    assert diff.max() <= 1e-4 * scale
+    assert np.all(res[True][2][:8][np.abs(x[:8]).max(1) > m.bound] == 0)
+    want_s, _ = _oracle_net(m).density(x)
+    np.testing.assert_allclose(res[True][0], want_s, rtol=2e-5, atol=1e-6)
+    # geo_feat gradients too (both outputs used), and batched shapes [..., 3]
+    xt = torch.from_numpy(x[:M - M % 4]).to(device).view(4, -1, 3).requires_grad_(True)
+    out = m.density(xt)
+    assert out["sigma"].shape == (4, (M - M % 4) // 4) and out["geo_feat"].shape == (4, (M - M % 4) // 4, 15)
+    (out["sigma"].sum() + (out["geo_feat"] ** 2).sum()).backward()
+    g_f = xt.grad.reshape(-1, 3).cpu().numpy()
+    m.fused = False
+    xt2 = torch.from_numpy(x[:M - M % 4]).to(device).view(4, -1, 3).requires_grad_(True)
+    out2 = m.density(xt2)
+    (out2["sigma"].sum() + (out2["geo_feat"] ** 2).sum()).backward()
+    m.fused = True
+    g_o = xt2.grad.reshape(-1, 3).cpu().numpy()
+    assert np.abs(g_f - g_o).max() <= 1e-4 * np.abs(g_o).max()
+
+
+def test_density_takes_the_operators_when_parameters_train(device):
+    sc = _scene(16, 16)
+    m = _linear_model(sc, device)
+    x = torch.rand(64, 3, device=device, requires_grad=True)
+    out = m.density(x)            # parameters require grad: autograd must reach them -> operator path
+    out["sigma"].sum().backward()
+    assert m.encoder.embeddings.grad is not None and m.sigma_net[0].weight.grad is not None
+    with torch.no_grad():
+        assert m.density(x)["sigma"].shape == (64,)          # no autograd: fused
+    assert m._fused_cache32 is not None
+
+
+def test_ffmlp_backbone_outside_autocast_raises_like_the_reference(device):
+    """nerf/network_ff.py without autocast: the reference's FFMLP is handed fp32 tensors (custom_fwd only casts under autocast,
+    ffmlp/ffmlp.py:18) and raises at CHECK_IS_HALF (ffmlp.cu:636-642).  The fused path must not render from its fp16 table copy
+    instead -- with a table that is not fp16-representable that would be a different image."""
+    sc = _scene(16, 16)
+    m = sc.build_model(device, backbone="ff", cuda_ray=False, fp16_table=False)
+    ro, rd = pinhole_rays(sc.poses[0], sc.intrinsics, 16, 16)
+    rot, rdt = torch.from_numpy(ro).to(device)[None], torch.from_numpy(rd).to(device)[None]
+    with torch.no_grad():
+        assert m.fused_model() is None
+        with pytest.raises(RuntimeError, match="half"):
+            m.render(rot, rdt, staged=True, bg_color=1, perturb=False, num_steps=32, upsample_steps=0)
+        with torch.autocast("cuda", dtype=torch.float16):
+            fm = m.fused_model()
+            assert fm is not None and not fm.f32
+            # under autocast the reference casts the table to half (gridencoder/grid.py:38-39): that copy is what is rendered
+            assert torch.equal(fm.emb16, m.encoder.embeddings.detach().half())
+            out = m.render(rot, rdt, staged=True, bg_color=1, perturb=False, num_steps=32, upsample_steps=0)
+            m.fused = False
+            ops = m.render(rot, rdt, staged=True, bg_color=1, perturb=False, num_steps=32, upsample_steps=0)
+    assert np.abs(out["image"].float().cpu().numpy() - ops["image"].float().cpu().numpy()).max() < 2e-3
