@@ -232,6 +232,10 @@ typedef struct ngp_model {
 } ngp_model;
 #define NGP_PREC_F16 0u
 #define NGP_PREC_F32 1u
+/* fp16 as NGP_PREC_F16, but the fused gather interpolates with the reference's c10::Half arithmetic (every product w * entry rounded to
+ * half, half running sum over the 8 corners, gridencoder.cu:169-172): the 32 features are then bit-identical to grid_encode's.  The
+ * default accumulates the corners in fp32 and rounds once (closer to the exact value, one instruction per corner instead of three). */
+#define NGP_PREC_F16_REF 2u
 
 /* fragment-major copy of model->sigma_weights / color_weights for the fused kernels (layout: render_fused.hip, k_pack_weights) */
 NGP_API size_t ngp_packed_weights_bytes(void);

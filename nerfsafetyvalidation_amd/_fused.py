@@ -77,6 +77,8 @@ class FusedModel:
         if enc.input_dim != 3 or enc.num_levels != 16 or enc.level_dim != 2:
             raise RuntimeError("fused renderer needs the 3-D, 16-level, 2-feature hash grid")
         self.f32 = bool(f32)
+        # fp16 only: interpolate with the reference's c10::Half corner arithmetic (NGP_PREC_F16_REF) instead of fp32 accumulation
+        self.ref_rounding = bool(getattr(net, "fused_reference_rounding", False)) and not self.f32
         if self.f32:
             # the reference reads the fp32 parameter itself outside autocast (gridencoder/grid.py:36-39): no copy, no per-cell records
             if enc.embeddings.dtype != torch.float32:
@@ -149,7 +151,8 @@ class FusedModel:
 
     def valid_for(self, net):
         return (_versions(self._watched) == self._snapshot and self.density_scale == float(net.density_scale)
-                and self.bound == float(net.bound) and self.emb16.device == net.encoder.embeddings.device)
+                and self.bound == float(net.bound) and self.emb16.device == net.encoder.embeddings.device
+                and (self.f32 or self.ref_rounding == bool(getattr(net, "fused_reference_rounding", False))))
 
     # ---- C structs -----------------------------------------------------------------------------------------
     def _struct(self, bitfield):
@@ -165,7 +168,7 @@ class FusedModel:
         m.cell_tables = _lib.ptr(self._cells) if self._cells is not None else None
         m.cell_levels = self._cell_levels
         m.packed_weights = _lib.ptr(self._packed) if self._packed is not None else None
-        m.precision = _lib.NGP_PREC_F32 if self.f32 else _lib.NGP_PREC_F16
+        m.precision = _lib.NGP_PREC_F32 if self.f32 else (_lib.NGP_PREC_F16_REF if self.ref_rounding else _lib.NGP_PREC_F16)
         return m
 
     def _ensure_packed(self):

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("NGP_HIP_LIB", os.path.join(_HERE, "libngp_hip.so"))   # (the override: A/B builds of experiments, scripts/build_variant.sh)
 
 NGP_F32, NGP_F16 = 0, 1
-NGP_PREC_F16, NGP_PREC_F32 = 0, 1          # ngp_model::precision
+NGP_PREC_F16, NGP_PREC_F32, NGP_PREC_F16_REF = 0, 1, 2          # ngp_model::precision
 
 _vp, _u32, _f32, _int, _sz = C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_size_t
 

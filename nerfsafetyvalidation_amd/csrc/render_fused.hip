@@ -107,14 +107,20 @@ struct NetArgs {
     const uint4* cells;
     uint32_t cell_steps;
     uint32_t cell_off[16];     // first record of a level
-    uint32_t dbg_shrink;       // diagnostics (debug flag bits 4-7): fold hashed levels into size >> n entries (timing only, wrong images)
-    uint32_t f32;              // ngp_model::precision == NGP_PREC_F32: `table` holds float pairs, `packed` float fragments (NetF32 below)
+    // bits 0-3: diagnostics (debug flag bits 4-7): fold hashed levels into size >> n entries (timing only, wrong images);
+    // bit 8: ngp_model::precision == NGP_PREC_F32 (`table` holds float pairs, `packed` float fragments: NetF32 below); bit 9: ... == NGP_PREC_F16_REF
+    // (host side only: selects the HACC kernel instantiations).  (One word: the struct is a kernel argument of the tuned render loop.)
+    uint32_t dbg_shrink;
+    __host__ __device__ bool f32() const { return (dbg_shrink & 256u) != 0; }
+    __host__ __device__ bool hacc() const { return (dbg_shrink & 512u) != 0; }
+    __host__ __device__ uint32_t shrink() const { return dbg_shrink & 15u; }
 };
 
 __host__ __device__ inline uint32_t sig_halfs(uint32_t mm) { return 2048 + mm * 4096 + 1024; }
+__host__ __device__ inline size_t net_w_bytes_f16(const NetArgs& na) { return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * 2; }
 // bytes of the packed forward weights of both nets (the LDS image every fused kernel starts with)
 __host__ __device__ inline size_t net_w_bytes(const NetArgs& na) {
-    return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * (na.f32 ? 4 : 2);
+    return (size_t)(sig_halfs(na.sig_mm) + sig_halfs(na.col_mm)) * (na.f32() ? 4 : 2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -235,8 +241,36 @@ __device__ __forceinline__ float fma_mix_hi(float w, uint32_t packed, float acc)
     return r;
 }
 
+// HALF_ACC (ngp_model::precision == NGP_PREC_F16_REF, `model.fused_reference_rounding`): the grid_encode operator's arithmetic instead --
+// every product rounded to fp16, fp16 running sum (c10::Half, gridencoder.cu:169-172): the features are then bit-identical to the
+// reference's, at three VALU instructions per corner and feature instead of one.
+template <bool HALF_ACC = false>
+__device__ __forceinline__ void corners_to_feature(const float (&fr)[3], const uint32_t (&raw)[8], bool oob, _Float16& f0, _Float16& f1) {
+    float a0 = 0.0f, a1 = 0.0f;
+    half2v hs = {(_Float16)0, (_Float16)0};
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const float wx = (idx & 1) ? fr[0] : 1 - fr[0];
+        const float wy = (idx & 2) ? fr[1] : 1 - fr[1];
+        const float wz = (idx & 4) ? fr[2] : 1 - fr[2];
+        const float w = (wx * wy) * wz;
+        if (HALF_ACC) {
+            // w * (float)entry in fp32 (x + (-0) = x: the fma with a -0 addend IS the fp32 product, signed zeros included; the
+            // conversion of the entry is part of the instruction), rounded to half -- two roundings, as c10::Half's operator* gives,
+            // not the single one of v_fma_mixlo_f16 -- then the half running sum of both channels in one packed add
+            half2v pr = {(_Float16)fma_mix_lo(w, raw[idx], -0.0f), (_Float16)fma_mix_hi(w, raw[idx], -0.0f)};
+            hs = hs + pr;
+        } else {
+            a0 = fma_mix_lo(w, raw[idx], a0);
+            a1 = fma_mix_hi(w, raw[idx], a1);
+        }
+    }
+    f0 = oob ? (_Float16)0 : (HALF_ACC ? hs[0] : (_Float16)a0);
+    f1 = oob ? (_Float16)0 : (HALF_ACC ? hs[1] : (_Float16)a1);
+}
+
 // density half: hash-grid encode + sigma net.  Returns sigma (meaningful in q == 0) and the sigma-net outputs 4q..4q+3 as fp16.
-template <int MODE>
+template <int MODE, bool HACC = false>
 __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y, float z,
                                             float& sigma, _Float16 (&s16)[4]) {
     const uint32_t q = lane >> 4;
@@ -295,6 +329,12 @@ __device__ __forceinline__ void net_density(const NetArgs& na, const _Float16* W
         // The fused path accumulates the 8 corners in fp32 (one v_fma_mix_f32 per corner and feature) and rounds the feature
         // to fp16 once; the grid_encode operator keeps the reference's c10::Half accumulation (8 roundings, :169-172) bit for
         // bit.  The difference is below one fp16 ulp of the feature and inside the fused path's documented tolerance.
+        if constexpr (HACC) {        // the reference's c10::Half accumulation (NGP_PREC_F16_REF)
+            _Float16 f0, f1;
+            corners_to_feature<true>(fr[i], raw[i], oob, f0, f1);
+            feat[2 * i] = f0; feat[2 * i + 1] = f1;
+            continue;
+        }
         float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
@@ -352,31 +392,8 @@ __device__ __forceinline__ void hashed_gather(const NetArgs& na, const LevelTab&
     }
 }
 
-// HALF_ACC (diagnostics only, ngp_debug_fused_features): the grid_encode operator's arithmetic instead -- every product rounded to
-// fp16, fp16 running sum (c10::Half, gridencoder.cu:169-172) -- to measure what the default's single rounding changes.
-template <bool HALF_ACC = false>
-__device__ __forceinline__ void corners_to_feature(const float (&fr)[3], const uint32_t (&raw)[8], bool oob, _Float16& f0, _Float16& f1) {
-    float a0 = 0.0f, a1 = 0.0f;
-    _Float16 h0 = (_Float16)0, h1 = (_Float16)0;
-#pragma unroll
-    for (int idx = 0; idx < 8; idx++) {
-        const float wx = (idx & 1) ? fr[0] : 1 - fr[0];
-        const float wy = (idx & 2) ? fr[1] : 1 - fr[1];
-        const float wz = (idx & 4) ? fr[2] : 1 - fr[2];
-        const float w = (wx * wy) * wz;
-        if (HALF_ACC) {
-            h0 = h0 + mul_round_f16(w, __builtin_bit_cast(_Float16, (uint16_t)(raw[idx] & 0xffffu)));
-            h1 = h1 + mul_round_f16(w, __builtin_bit_cast(_Float16, (uint16_t)(raw[idx] >> 16)));
-        } else {
-            a0 = fma_mix_lo(w, raw[idx], a0);
-            a1 = fma_mix_hi(w, raw[idx], a1);
-        }
-    }
-    f0 = oob ? (_Float16)0 : (HALF_ACC ? h0 : (_Float16)a0);
-    f1 = oob ? (_Float16)0 : (HALF_ACC ? h1 : (_Float16)a1);
-}
-
 // same values and arithmetic as net_density<2>; `pre` holds this tile's hashed-level entries on entry and the next tile's on exit
+template <bool HACC = false>
 __device__ __forceinline__ void net_density_piped(const NetArgs& na, const _Float16* Wlds, const LevelTab& lt, uint32_t lane, float x, float y,
                                                   float z, float nx, float ny, float nz, uint32_t (&pre)[8], float& sigma,
                                                   _Float16 (&s16)[4]) {
@@ -408,7 +425,7 @@ __device__ __forceinline__ void net_density_piped(const NetArgs& na, const _Floa
     half8 feat;
     {
         _Float16 f0, f1;
-        corners_to_feature(fr[3], pre, oob, f0, f1);
+        corners_to_feature<HACC>(fr[3], pre, oob, f0, f1);
         feat[6] = f0; feat[7] = f1;
     }
     // (unconditional: a branch here makes the compiler wait for ALL outstanding loads at the join; the last tile re-gathers its own entries)
@@ -417,7 +434,7 @@ __device__ __forceinline__ void net_density_piped(const NetArgs& na, const _Floa
     for (int i = 0; i < 3; i++) {
         const uint32_t raw[8] = {rec[i][0].x, rec[i][0].y, rec[i][0].z, rec[i][0].w, rec[i][1].x, rec[i][1].y, rec[i][1].z, rec[i][1].w};
         _Float16 f0, f1;
-        corners_to_feature(fr[i], raw, oob, f0, f1);
+        corners_to_feature<HACC>(fr[i], raw, oob, f0, f1);
         feat[2 * i] = f0; feat[2 * i + 1] = f1;
     }
     const half8* Ws = reinterpret_cast<const half8*>(Wlds);
@@ -736,8 +753,9 @@ __device__ __forceinline__ void relu_mask32(const f32x4 (&acc)[4], const f32x4 (
 }
 
 // stage packed weights + level table into LDS (all threads of the block)
-__device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels& lv, void* Wlds, LevelTab* lt) {
-    const uint32_t n16 = (uint32_t)(net_w_bytes(na) / 16);  // 16-byte chunks
+// (w_bytes: the caller's net_w_bytes(na), or the fp16 constant expression in the kernels that only exist for fp16)
+__device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels& lv, void* Wlds, LevelTab* lt, size_t w_bytes) {
+    const uint32_t n16 = (uint32_t)(w_bytes / 16);  // 16-byte chunks
     const uint4* src = reinterpret_cast<const uint4*>(na.packed);
     uint4* dst = reinterpret_cast<uint4*>(Wlds);
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
@@ -749,7 +767,7 @@ __device__ __forceinline__ void stage_block(const NetArgs& na, const GridLevels&
         lt->size[l] = size;
         lt->a1[l] = lv.hashed[l] ? 2654435761u : lv.mul1[l];
         lt->a2[l] = lv.hashed[l] ? 805459861u : lv.mul2[l];
-        lt->mask[l] = lv.mode[l] == 1 ? (size >> na.dbg_shrink) - 1 : 0xFFFFFFFFu;
+        lt->mask[l] = lv.mode[l] == 1 ? (size >> na.shrink()) - 1 : 0xFFFFFFFFu;
         lt->flags[l] = (uint32_t)lv.hashed[l] | (lv.mode[l] == 2 ? 2u : 0u);
         lt->cell_off[l] = na.cell_off[l];
         lt->cell_res[l] = lv.resolution[l];
@@ -775,14 +793,16 @@ __device__ __forceinline__ void mlp_in_bwd(const half8* Wt, uint32_t lane, const
 __device__ __forceinline__ void relu_mask_pack(const f32x4 (&acc)[4], const half8 (&h)[2], half8 (&g)[2]);
 __device__ __forceinline__ void sh4_quarter_vjp(uint32_t q, float x, float y, float z, const float (&g)[4], float (&o)[3]);
 
-template <int MODE_>
+template <int MODE_, bool HACC_ = false>
 struct NetF16 {
     static constexpr int MODE = MODE_;
+    static constexpr bool HACC = HACC_;        // the reference's c10::Half corner accumulation (NGP_PREC_F16_REF)
     static constexpr bool kF32 = false;
     typedef _Float16 geo_t;
+    static __host__ __device__ size_t w_bytes(const NetArgs& na) { return net_w_bytes_f16(na); }
     static __device__ __forceinline__ void density(const NetArgs& na, const char* W, const LevelTab& lt, uint32_t lane, float x, float y, float z,
                                                    float& sigma, geo_t (&s)[4]) {
-        net_density<MODE>(na, reinterpret_cast<const _Float16*>(W), lt, lane, x, y, z, sigma, s);
+        net_density<MODE, HACC>(na, reinterpret_cast<const _Float16*>(W), lt, lane, x, y, z, sigma, s);
     }
     static __device__ __forceinline__ void color(const NetArgs& na, const char* W, uint32_t lane, float dx, float dy, float dz, const geo_t (&s)[4],
                                                  float& cr, float& cg, float& cb) {
@@ -807,7 +827,7 @@ struct NetF16 {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             _Float16 f0, f1;
-            corners_to_feature(t.fr[i], t.raw[i], t.oob, f0, f1);
+            corners_to_feature<HACC>(t.fr[i], t.raw[i], t.oob, f0, f1);
             feat[2 * i] = f0; feat[2 * i + 1] = f1;
         }
         mlp_in(Ws, lane, feat, t.hs[0]);                   // (indices stay compile-time constants: register arrays)
@@ -927,6 +947,7 @@ struct NetF32 {
     static constexpr int MODE = MODE_;
     static constexpr bool kF32 = true;
     typedef float geo_t;
+    static __host__ __device__ size_t w_bytes(const NetArgs& na) { return 2 * net_w_bytes_f16(na); }
     static __device__ __forceinline__ void features(const NetArgs& na, const LevelTab& lt, uint32_t q, float x, float y, float z, float (&feat)[8]) {
         float2 raw[4][8];
         float fr[4][3];
@@ -1070,8 +1091,8 @@ template <int MODE, bool HALF_ACC>
 __global__ void __launch_bounds__(256) k_debug_features(NetArgs na, GridLevels lv, const float* __restrict__ xyzs, uint32_t M, _Float16* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
-    stage_block(na, lv, Wlds, lt);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes_f16(na));
+    stage_block(na, lv, Wlds, lt, net_w_bytes_f16(na));
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t tile = wave; tile < (M + 15) / 16; tile += n_waves) {
@@ -1093,7 +1114,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_debug_features32(NetArgs na, GridLevels lv, const float* __restrict__ xyzs, uint32_t M, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
-    stage_block(na, lv, smem, lt);
+    stage_block(na, lv, smem, lt, net_w_bytes(na));
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t tile = wave; tile < (M + 15) / 16; tile += n_waves) {
@@ -1116,8 +1137,8 @@ __global__ void __launch_bounds__(256) k_network_forward(NetArgs na, GridLevels 
                                                          float* __restrict__ rgbs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char* Wlds = smem;
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
-    stage_block(na, lv, smem, lt);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + NET::w_bytes(na));
+    stage_block(na, lv, smem, lt, NET::w_bytes(na));
     const uint32_t lane = threadIdx.x & 63, c = lane & 15;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_tiles = (M + 15) / 16;
@@ -1144,8 +1165,8 @@ __global__ void __launch_bounds__(256) k_network_density(NetArgs na, GridLevels 
                                                          float* __restrict__ sigmas, float* __restrict__ geo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char* Wlds = smem;
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
-    stage_block(na, lv, smem, lt);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + NET::w_bytes(na));
+    stage_block(na, lv, smem, lt, NET::w_bytes(na));
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_tiles = (M + 15) / 16;
@@ -1173,7 +1194,7 @@ __global__ void __launch_bounds__(256) k_network_density_bwd(NetArgs na, GridLev
                                                              const float* __restrict__ xyzs, uint32_t M, const float* __restrict__ g_sigma,
                                                              const float* __restrict__ g_geo, float* __restrict__ grad_xyzs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t w_bytes = net_w_bytes(na);
+    const size_t w_bytes = NET::w_bytes(na);
     const size_t ws_bytes = NET::kF32 ? (size_t)bwd_floats(na.sig_mm) * 4 : (size_t)bwd_halfs(na.sig_mm) * 2;   // the sigma net's transposed fragments only
     const char* Wlds = smem;
     char* Wb = smem + w_bytes;
@@ -1183,7 +1204,7 @@ __global__ void __launch_bounds__(256) k_network_density_bwd(NetArgs na, GridLev
         uint4* dst = reinterpret_cast<uint4*>(Wb);
         for (uint32_t i = threadIdx.x; i < ws_bytes / 16; i += blockDim.x) dst[i] = src[i];
     }
-    stage_block(na, lv, smem, lt);
+    stage_block(na, lv, smem, lt, w_bytes);
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_tiles = (M + 15) / 16;
@@ -1235,8 +1256,8 @@ __global__ void __launch_bounds__(256, NET::kF32 ? 2 : 4) k_render_uniform(NetAr
                                                            float* __restrict__ sigmas, float* __restrict__ rgbs, float aabb_lo, float aabb_hi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char* Wlds = smem;
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
-    stage_block(na, lv, smem, lt);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + NET::w_bytes(na));
+    stage_block(na, lv, smem, lt, NET::w_bytes(na));
     const uint32_t lane = threadIdx.x & 63, c = lane & 15;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t ray = wave; ray < N; ray += n_waves) {
@@ -1331,8 +1352,8 @@ __global__ void __launch_bounds__(256, NET::kF32 ? 2 : 4) k_render_uniform_x16(N
                                                                const float* __restrict__ z_in, _Float16* __restrict__ geo_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char* Wlds = smem;
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
-    stage_block(na, lv, smem, lt);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + NET::w_bytes(na));
+    stage_block(na, lv, smem, lt, NET::w_bytes(na));
     const uint32_t lane = threadIdx.x & 63, c = lane & 15;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_groups = (N + 15) / 16;
@@ -1456,8 +1477,8 @@ __global__ void __launch_bounds__(256, 4) k_composite_merged_x16(NetArgs na, Gri
                                                                  float* __restrict__ sigmas, float* __restrict__ rgbs, uint32_t frame_w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
-    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes(na));
-    stage_block(na, lv, Wlds, lt);
+    LevelTab* lt = reinterpret_cast<LevelTab*>(smem + net_w_bytes_f16(na));
+    stage_block(na, lv, Wlds, lt, net_w_bytes_f16(na));
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_groups = (N + 15) / 16, Tm = T + U;
@@ -1548,10 +1569,10 @@ __global__ void __launch_bounds__(256) k_render_upsample(NetArgs na, GridLevels 
     // sc_in: sigma of the uniform samples, evaluated by k_render_uniform_x16<DENS> (tiles across rays);  zf_out: stop after the resampling
     // and hand the new depths over.  Both group-major (frame_w as in that launch): the middle launch of the large-batch form.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t w_bytes = net_w_bytes(na);
+    const size_t w_bytes = net_w_bytes_f16(na);
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
-    stage_block(na, lv, Wlds, lt);
+    stage_block(na, lv, Wlds, lt, w_bytes);
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const uint32_t Tm = T + U;
     float* zc = reinterpret_cast<float*>(smem + w_bytes + sizeof(LevelTab)) + (size_t)wid * (5 * T + 4 * U);
@@ -1858,7 +1879,7 @@ constexpr uint32_t kGradMaxT = 1024;
 template <class NET, int GW>
 __global__ void __launch_bounds__(GW * 64, 1) k_render_uniform_bwd(NetArgs na, GridLevels lv, GradArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t w_bytes = net_w_bytes(na);
+    const size_t w_bytes = NET::w_bytes(na);
     const size_t wb_bytes = NET::wb_bytes(na);
     const char* Wlds = smem;
     char* Wb = smem + w_bytes;
@@ -1869,7 +1890,7 @@ __global__ void __launch_bounds__(GW * 64, 1) k_render_uniform_bwd(NetArgs na, G
         uint4* dst = reinterpret_cast<uint4*>(Wb);
         for (uint32_t i = threadIdx.x; i < wb_bytes / 16; i += blockDim.x) dst[i] = src[i];
     }
-    stage_block(na, lv, smem, lt);
+    stage_block(na, lv, smem, lt, w_bytes);
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     const uint32_t T = ga.T;
     float* s_sig = store + (size_t)wid * 3 * T;      // pass 1: sigma (raw);  after the scan: dL/dsigma
@@ -2118,7 +2139,7 @@ __device__ __forceinline__ void dump_row(const RenderArgs& ra, uint32_t entry, i
 }
 
 // LIN: power-of-two grid with the linear copies of the occupancy bits (Dda::probe_lin); otherwise the Morton-order originals
-template <int MODE, bool LIN>
+template <int MODE, bool LIN, bool HACC = false>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
@@ -2127,14 +2148,14 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
     const uint32_t n_chunks = (n_alive + 63) / 64;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t w_bytes = net_w_bytes(na);
+    const size_t w_bytes = net_w_bytes_f16(na);
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
     WaveSlab* slabs = reinterpret_cast<WaveSlab*>(smem + w_bytes + sizeof(LevelTab));
     uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(smem + w_bytes + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab));
     for (uint32_t i = threadIdx.x; i < ra.coarse_words; i += blockDim.x) coarse_lds[i] = ra.coarse[i];
     const uint32_t* coarse = ra.coarse_words ? coarse_lds : nullptr;
-    stage_block(na, lv, Wlds, lt);   // the only workgroup barrier: waves are independent from here on
+    stage_block(na, lv, Wlds, lt, w_bytes);   // the only workgroup barrier: waves are independent from here on
 
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15;
     WaveSlab& S = slabs[wid];
@@ -2280,7 +2301,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                 if (ra.stamps) {   // diagnostics: split the tile into encode+sigma net and colour net, count tile fill
                     const unsigned long long ta = __builtin_amdgcn_s_memtime();
                     _Float16 s16[4];
-                    net_density<MODE>(na, Wlds, *lt, lane, x, y, z, sg, s16);
+                    net_density<MODE, HACC>(na, Wlds, *lt, lane, x, y, z, sg, s16);
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     const unsigned long long tb = __builtin_amdgcn_s_memtime();
                     net_color(na, Wlds, lane, dx, dy, dz, s16, r, g, b);
@@ -2301,10 +2322,12 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                     const float nz = clampf(fmaf(tn, S.od[rn][5], S.od[rn][2]), -na.bound, na.bound);
                     if (tile == 0) hashed_gather(na, *lt, (lane >> 4) + 12, x, y, z, pre);
                     _Float16 s16[4];
-                    net_density_piped(na, Wlds, *lt, lane, x, y, z, nx, ny, nz, pre, sg, s16);
+                    net_density_piped<HACC>(na, Wlds, *lt, lane, x, y, z, nx, ny, nz, pre, sg, s16);
                     net_color(na, Wlds, lane, dx, dy, dz, s16, r, g, b);
                 } else {
-                    net_tile<MODE>(na, Wlds, *lt, lane, x, y, z, dx, dy, dz, sg, r, g, b);
+                    _Float16 s16[4];
+                    net_density<MODE, HACC>(na, Wlds, *lt, lane, x, y, z, sg, s16);
+                    net_color(na, Wlds, lane, dx, dy, dz, s16, r, g, b);
                 }
                 if (lane < 16 && valid) {
                     S.sig[slot] = na.density_scale * sg;   // renderer.py:365
@@ -2840,9 +2863,8 @@ static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* p
     na.inv_two_bound = 1.0f / (2 * m->bound);
     na.density_scale = m->density_scale;
     na.align_corners = m->align_corners;
-    na.dbg_shrink = dbg.shrink();
-    NGP_REQUIRE(m->precision == NGP_PREC_F16 || m->precision == NGP_PREC_F32, "ngp_model: unknown precision %u", m->precision);
-    na.f32 = m->precision == NGP_PREC_F32 ? 1u : 0u;
+    NGP_REQUIRE(m->precision <= NGP_PREC_F16_REF, "ngp_model: unknown precision %u", m->precision);
+    na.dbg_shrink = dbg.shrink() | (m->precision == NGP_PREC_F32 ? 256u : 0u) | (m->precision == NGP_PREC_F16_REF ? 512u : 0u);
     na.cells = nullptr;
     na.cell_steps = 0;
     for (int l = 0; l < 16; l++) na.cell_off[l] = 0;
@@ -2850,7 +2872,7 @@ static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* p
         NGP_REQUIRE(m->cell_levels % 4 == 0 && m->cell_levels <= 16, "ngp_model: cell_levels must be 0, 4, 8, 12 or 16 (got %u)", m->cell_levels);
         NGP_REQUIRE(cell_records(lv, m->cell_levels, na.cell_off) != 0, "ngp_model: the cell tables of %u levels exceed 2^32 records", m->cell_levels);
         NGP_REQUIRE(((uintptr_t)m->cell_tables & 15) == 0, "ngp_model: cell_tables must be 16-byte aligned");
-        NGP_REQUIRE(!na.f32, "ngp_model: per-cell records exist for the fp16 table only");
+        NGP_REQUIRE(!na.f32(), "ngp_model: per-cell records exist for the fp16 table only");
         if (m->cell_levels == 12 && !needs_generic(lv)) {   // the kernels are specialised for exactly 12 expanded levels
             na.cells = reinterpret_cast<const uint4*>(m->cell_tables);
             na.cell_steps = 3;
@@ -2861,10 +2883,12 @@ static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* p
 
 static size_t weights_bytes(const NetArgs& na) { return net_w_bytes(na); }
 
-// kernel variant of a model: 0 / 1 / 2 = fp16 (AND-reduced indices, generic modulo, per-cell records), 3 / 4 = fp32 (AND, generic)
+// kernel variant of a model: 0 / 1 / 2 = fp16 (AND-reduced indices, generic modulo, per-cell records), 3 / 4 = fp32 (AND, generic),
+// 5 / 6 / 7 = fp16 with the reference's corner rounding
 static int net_variant(const NetArgs& na, const GridLevels& lv) {
     const bool gen = needs_generic(lv);
-    return na.f32 ? (gen ? 4 : 3) : (gen ? 1 : (na.cells ? 2 : 0));
+    if (na.f32()) return gen ? 4 : 3;
+    return (gen ? 1 : (na.cells ? 2 : 0)) + (na.hacc() ? 5 : 0);
 }
 // runs STMT with NET bound to the policy class of `variant`
 #define NGP_WITH_NET(variant, ...)                                           \
@@ -2873,7 +2897,10 @@ static int net_variant(const NetArgs& na, const GridLevels& lv) {
         case 1: { using NET = NetF16<1>; __VA_ARGS__; } break;               \
         case 2: { using NET = NetF16<2>; __VA_ARGS__; } break;               \
         case 3: { using NET = NetF32<0>; __VA_ARGS__; } break;               \
-        default: { using NET = NetF32<1>; __VA_ARGS__; } break;              \
+        case 4: { using NET = NetF32<1>; __VA_ARGS__; } break;               \
+        case 5: { using NET = NetF16<0, true>; __VA_ARGS__; } break;         \
+        case 6: { using NET = NetF16<1, true>; __VA_ARGS__; } break;         \
+        default: { using NET = NetF16<2, true>; __VA_ARGS__; } break;        \
     }
 
 extern "C" {
@@ -2977,7 +3004,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const _Float16* packed = model && model->packed_weights ? (const _Float16*)model->packed_weights : ctx->packed;
     int rc = fill_net(model, dbg, packed, na, lv);
     if (rc) return rc;
-    NGP_REQUIRE(!na.f32, "render_rays: the occupancy-grid loop is built for the fp16 network (ngp_model::precision == NGP_PREC_F16)");
+    NGP_REQUIRE(!na.f32(), "render_rays: the occupancy-grid loop is built for the fp16 network (ngp_model::precision == NGP_PREC_F16)");
     if (!model->packed_weights) {
         const uint32_t n_packed = sig_halfs(na.sig_mm) + sig_halfs(na.col_mm);
         k_pack_weights<<<div_up(n_packed, 256), 256, 0, s>>>((const _Float16*)model->sigma_weights, na.sig_mm,
@@ -3051,14 +3078,18 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     }
     const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab) + (use_coarse ? coarse_bytes : 0);
     const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<0, false>), 160 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<1, false>), 160 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<2, false>), 160 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<0, true>), 160 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<1, true>), 160 * 1024);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_iter<2, true>), 160 * 1024);
     const bool generic = needs_generic(lv);
     const bool use_cells = na.cells != nullptr;
+    // the kernel instantiation of this call: (index recipe) x (occupancy bit layout) x (corner rounding)
+    typedef void (*IterKernel)(NetArgs, GridLevels, RenderArgs);
+    const int mode = generic ? 1 : (use_cells ? 2 : 0);
+    static const IterKernel kIter[2][2][3] = {
+        {{k_render_iter<0, false, false>, k_render_iter<1, false, false>, k_render_iter<2, false, false>},
+         {k_render_iter<0, true, false>, k_render_iter<1, true, false>, k_render_iter<2, true, false>}},
+        {{k_render_iter<0, false, true>, k_render_iter<1, false, true>, k_render_iter<2, false, true>},
+         {k_render_iter<0, true, true>, k_render_iter<1, true, true>, k_render_iter<2, true, true>}}};
+    const IterKernel iter_kernel = kIter[na.hacc() ? 1 : 0][lin ? 1 : 0][mode];
+    ensure_dynamic_lds(reinterpret_cast<const void*>(iter_kernel), 160 * 1024);
     NGP_REQUIRE(lds <= 160 * 1024, "render_rays: LDS budget exceeded (%zu bytes)", lds);
 
     uint32_t ub = N;          // host-side upper bound of n_alive
@@ -3078,12 +3109,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.death_shards = ctx->death_shards + (size_t)cur * kDeathShards * kSpecK;
         {
             ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
-            if (generic && lin) k_render_iter<1, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else if (generic) k_render_iter<1, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else if (use_cells && lin) k_render_iter<2, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else if (use_cells) k_render_iter<2, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else if (lin) k_render_iter<0, true><<<blocks, kThreads, lds, s>>>(na, lv, ra);
-            else k_render_iter<0, false><<<blocks, kThreads, lds, s>>>(na, lv, ra);
+            iter_kernel<<<blocks, kThreads, lds, s>>>(na, lv, ra);
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
@@ -3192,7 +3218,7 @@ int ngp_debug_fused_features(const ngp_model* model, const float* xyzs, uint32_t
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
     uint32_t blocks = div_up(div_up(M, 16), 4);
     if (blocks > 1024) blocks = 1024;
-    if (na.f32) {   // `features` is float [M, 32] then; one arithmetic only (the operator's)
+    if (na.f32()) {   // `features` is float [M, 32] then; one arithmetic only (the operator's)
         if (needs_generic(lv)) k_debug_features32<1><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, (float*)features);
         else k_debug_features32<0><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, (float*)features);
         return check_launch("debug_fused_features");
@@ -3314,7 +3340,7 @@ int ngp_render_upsample(const ngp_model* model, const float* rays_o, const float
     GridLevels lv;
     int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
-    NGP_REQUIRE(!na.f32, "render_upsample: built for the fp16 network (ngp_model::precision == NGP_PREC_F16)");
+    NGP_REQUIRE(!na.f32(), "render_upsample: built for the fp16 network (ngp_model::precision == NGP_PREC_F16)");
     const size_t fixed = weights_bytes(na) + sizeof(LevelTab), per_wave = ((size_t)5 * T + (size_t)4 * U) * sizeof(float);
     const size_t budget = 160 * 1024 - 1024;
     NGP_REQUIRE(fixed + per_wave <= budget, "render_upsample: num_steps %u + upsample_steps %u need %zu bytes of LDS per ray, %zu are available", T, U,
@@ -3413,15 +3439,15 @@ int ngp_pack_weights_bwd(const ngp_model* model, void* out, ngp_stream_t stream)
 }
 
 // the fp32 backward kernels keep at most 1 / 2 hidden layers' activations (NetF32::Tape; nerf/network.py has 0 / 1)
-static bool bwd_shape_ok(const NetArgs& na) { return !na.f32 || (na.sig_mm <= NetF32<0>::kMaxSigMM && na.col_mm <= NetF32<0>::kMaxColMM); }
+static bool bwd_shape_ok(const NetArgs& na) { return !na.f32() || (na.sig_mm <= NetF32<0>::kMaxSigMM && na.col_mm <= NetF32<0>::kMaxColMM); }
 
 size_t ngp_render_uniform_backward_lds(const ngp_model* model, uint32_t T) {
     if (!model) return 0;
     NetArgs na = {};
-    na.sig_mm = model->sigma_hidden_mm; na.col_mm = model->color_hidden_mm; na.f32 = model->precision == NGP_PREC_F32;
+    na.sig_mm = model->sigma_hidden_mm; na.col_mm = model->color_hidden_mm; na.dbg_shrink = model->precision == NGP_PREC_F32 ? 256u : 0u;
     if (!bwd_shape_ok(na)) return (size_t)-1;
-    const size_t wb = na.f32 ? NetF32<0>::wb_bytes(na) : NetF16<0>::wb_bytes(na);
-    return net_w_bytes(na) + wb + sizeof(LevelTab) + (size_t)(na.f32 ? 4 : kGradWaves) * 3 * T * 4;
+    const size_t wb = na.f32() ? NetF32<0>::wb_bytes(na) : NetF16<0>::wb_bytes(na);
+    return net_w_bytes(na) + wb + sizeof(LevelTab) + (size_t)(na.f32() ? 4 : kGradWaves) * 3 * T * 4;
 }
 
 int ngp_render_uniform_backward(const ngp_model* model, const void* packed_weights_bwd, const float* rays_o, const float* rays_d, const float* nears,
@@ -3445,7 +3471,7 @@ int ngp_render_uniform_backward(const ngp_model* model, const void* packed_weigh
     ProfScope prof("render_uniform_backward", s, (double)N * T);
     // four rays per workgroup: always in fp32; in fp16 while that still gives every CU at most two rounds of work
     static const int force_gw = getenv("NGP_GRAD_WAVES") ? atoi(getenv("NGP_GRAD_WAVES")) : 0;     // diagnostics
-    const bool four = na.f32 || (force_gw ? force_gw == 4 : N <= 2048);
+    const bool four = na.f32() || (force_gw ? force_gw == 4 : N <= 2048);
     uint32_t blocks = div_up(N, four ? 4 : kGradWaves);
     if (blocks > 512) blocks = 512;
     NGP_WITH_NET(net_variant(na, lv), {
@@ -3492,7 +3518,7 @@ int ngp_network_density_backward(const ngp_model* model, const void* packed_weig
     int rc = fill_net(model, debug_snapshot(nullptr), (const _Float16*)model->packed_weights, na, lv);
     if (rc) return rc;
     NGP_REQUIRE(bwd_shape_ok(na), "network_density_backward: the fp32 form supports at most 1 hidden matmul in the sigma net (got %u)", na.sig_mm);
-    const size_t ws = na.f32 ? (size_t)bwd_floats(na.sig_mm) * 4 : (size_t)bwd_halfs(na.sig_mm) * 2;
+    const size_t ws = na.f32() ? (size_t)bwd_floats(na.sig_mm) * 4 : (size_t)bwd_halfs(na.sig_mm) * 2;
     const size_t lds = weights_bytes(na) + ws + sizeof(LevelTab);
     NGP_REQUIRE(lds <= 160 * 1024, "network_density_backward: LDS budget exceeded (%zu bytes)", lds);
     uint32_t blocks = div_up(div_up(M, 16), 4);

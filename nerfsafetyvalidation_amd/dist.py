@@ -68,15 +68,73 @@ def gather_views(local, n_total, group=None, force=False):
     return gather_views_start(local, n_total, group, force).finish()
 
 
-def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None, in_flight=1, device=None, force_collective=False):
-    """render_view(i) -> dict of tensors for global view i (e.g. {'image': [H*W,3], 'depth': [H*W]}).
-    Each rank renders its contiguous block of views; one all_gather per key returns all views everywhere.
-    in_flight > 1 (GPU only, `device` required): that many views of this rank are rendered concurrently, each by its own
-    render_view call on its own host thread and stream (pipeline.FramePipeline); the collectives stay on this thread."""
+def _all_gather_padded(local, n_max, group=None):
+    """all_gather of per-rank stacks that may differ in length: local [n_local <= n_max, ...] -> [world, n_max, ...] on local's device
+    (rows beyond a rank's n_local are padding).  gloo with device tensors stages through the host (rehearsal mode)."""
+    world = dist.get_world_size(group)
+    pad = n_max - local.shape[0]
+    if pad > 0:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    device = local.device
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        local = local.contiguous().cpu()
+    out = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out.view(world, n_max, *local.shape[1:]).to(device)
+
+
+def render_frame_sharded(render_rows, H, group=None, rank=None, world_size=None, strip=8):
+    """ONE frame on all ranks ("row-tiles of one frame when fewer frames than GPUs"; the reference walks a frame in
+    4096-ray chunks on one GPU, nerf/renderer.py:566-575).  Rank r renders the `strip`-row strips s with s % world == r --
+    interleaved, because occupancy makes the cost of a strip uneven -- through render_rows(rows) -> dict of tensors [len(rows), ...]
+    (one entry per image row), then one all_gather per key puts the rows back in frame order on every rank."""
     if rank is None:
         rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     if world_size is None:
         world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    mine = shard_rows(H, rank, world_size, strip)
+    out = render_rows(mine)
+    if world_size == 1:
+        return out
+    owners = [shard_rows(H, r, world_size, strip) for r in range(world_size)]
+    n_max = max(len(o) for o in owners)
+    frame = {}
+    for key, val in out.items():
+        assert val.shape[0] == len(mine), f"render_rows must return one entry per row for {key!r}"
+        parts = _all_gather_padded(val, n_max, group)
+        full = val.new_empty((H,) + tuple(val.shape[1:]))
+        for r, rows in enumerate(owners):
+            if rows:
+                full[torch.as_tensor(rows, device=val.device)] = parts[r, :len(rows)]
+        frame[key] = full
+    return frame
+
+
+def render_views_sharded(render_view, n_views, group=None, rank=None, world_size=None, in_flight=1, device=None, force_collective=False,
+                         render_view_rows=None, H=None):
+    """render_view(i) -> dict of tensors for global view i (e.g. {'image': [H*W,3], 'depth': [H*W]}).
+    Each rank renders its contiguous block of views; one all_gather per key returns all views everywhere.
+    in_flight > 1 (GPU only, `device` required): that many views of this rank are rendered concurrently, each by its own
+    render_view call on its own host thread and stream (pipeline.FramePipeline); the collectives stay on this thread.
+    Fewer views than ranks: with render_view_rows(i, rows) -> dict of [len(rows), ...] tensors (and H, the rows per frame) every view is
+    rendered by ALL ranks in interleaved row strips (render_frame_sharded) and comes back as [n_views, H, ...]; without it the ranks
+    beyond n_views own nothing and only enter the collectives."""
+    initialised = dist.is_available() and dist.is_initialized()
+    group_rank = dist.get_rank(group) if initialised else 0
+    if rank is None:
+        rank = group_rank
+    if world_size is None:
+        world_size = dist.get_world_size(group) if initialised else 1
+    if n_views == 0:
+        return {}                     # (every rank: nothing to render, no collective to enter)
+    nccl = initialised and world_size > 1 and dist.get_backend(group) == "nccl"
+    if nccl and device is None:
+        device = torch.device("cuda", torch.cuda.current_device())     # RCCL moves device tensors only
+    if n_views < world_size and world_size > 1 and render_view_rows is not None:
+        if H is None:
+            raise ValueError("render_views_sharded: H (rows per frame) is required with render_view_rows")
+        frames = [render_frame_sharded(lambda rows, i=i: render_view_rows(i, rows), H, group, rank, world_size) for i in range(n_views)]
+        return {k: torch.stack([f[k] for f in frames], 0) for k in frames[0]}
     lo, hi = shard_range(n_views, rank, world_size)
     if in_flight > 1 and hi - lo > 1:
         from .pipeline import FramePipeline
@@ -94,10 +152,10 @@ def render_views_sharded(render_view, n_views, group=None, rank=None, world_size
         outs = [render_view(i) for i in range(lo, hi)]
     if n_views < world_size and world_size > 1:
         # some ranks have no view (e.g. one frame on 8 GPUs): they still have to enter every all_gather with a zero-row tensor of
-        # the right trailing shape, so rank 0 (which always owns a view) shares the schema first.  Only in this case.
-        schema = [[(k, tuple(v.shape), v.dtype) for k, v in outs[0].items()] if rank == 0 else None]
+        # the right trailing shape, so the group's rank 0 (which always owns a view) shares the schema first.  Only in this case.
+        schema = [[(k, tuple(v.shape), v.dtype) for k, v in outs[0].items()] if group_rank == 0 else None]
         dist.broadcast_object_list(schema, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
-                                   device=device if dist.get_backend(group) == "nccl" else None)
+                                   device=device if nccl else None)
         if not outs:
             dev = device if device is not None else "cpu"
             empty = {k: torch.empty((0,) + shape, dtype=dtype, device=dev) for k, shape, dtype in schema[0]}

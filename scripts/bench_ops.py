@@ -61,7 +61,9 @@ print(json.dumps({"op": "ffmlp_backward 32-64-64-16 (activation chain + split-K 
                   "rows_per_s": round(Bf / ms_b * 1e3), "tflops": round(flops_b / ms_b / 1e9, 1)}))
 if os.environ.get("NGP_DBG_FLAGS"):
     lib.ngp_debug_disable_march_queue(int(os.environ["NGP_DBG_FLAGS"]))   # A/B diagnostics (bits 4-7: fold the hashed levels)
-sc = StonehengeScene(H=64, W=64, bound=2); model = sc.build_model(dev); fm = model.fused_model()
+sc = StonehengeScene(H=64, W=64, bound=2); model = sc.build_model(dev)
+with torch.autocast("cuda", dtype=torch.float16):
+    fm = model.fused_model()          # (the fp16 snapshot: what the model hands out under autocast)
 xyz = (x * 4 - 2).contiguous(); dirs = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
 ms, _ = timed("network_forward", lambda: fm.network_forward(xyz, dirs), reps=10)
 print(json.dumps({"op": "network_forward (fused encode+MLPs)", "B": B, "inputs": mode, "ms": round(ms, 4), "points_per_s": round(B / ms * 1e3),

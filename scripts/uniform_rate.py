@@ -11,7 +11,8 @@ dev = torch.device("cuda:0")
 sc = StonehengeScene(H=800, W=800, bound=2)
 model = sc.build_model(dev, cuda_ray=False)
 poses = torch.from_numpy(sc.poses).to(dev)
-fm = model.fused_model()
+with torch.autocast("cuda", dtype=torch.float16):
+    fm = model.fused_model()          # (the fp16 snapshot: what the model hands out under autocast)
 with torch.no_grad():
     r = get_rays(poses[3:4], sc.intrinsics, 800, 800)
     o, d = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()

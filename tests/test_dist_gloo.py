@@ -73,3 +73,52 @@ def test_single_process_is_identity():
     out = render_views_sharded(_fake_view, 3)
     assert out["image"].shape == (3, 12, 3)
     assert torch.equal(out["depth"][2], _fake_view(2)["depth"])
+
+
+def _fake_rows(i, rows, W=6):
+    """rows of a deterministic H x W "frame" of view i: value = 1000 i + 10 row + column"""
+    r = torch.as_tensor(rows, dtype=torch.float32)[:, None]
+    img = 1000.0 * i + 10.0 * r + torch.arange(W, dtype=torch.float32)[None, :]
+    return {"image": img[..., None].repeat(1, 1, 3), "depth": img}
+
+
+def _rows_worker(rank, world, port, H, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerfsafetyvalidation_amd.dist import render_frame_sharded, render_views_sharded, shard_rows
+        asked = []
+
+        def render_rows(rows):
+            asked.append(list(rows))
+            return _fake_rows(3, rows)
+
+        frame = render_frame_sharded(render_rows, H)
+        want = _fake_rows(3, list(range(H)))
+        ok = asked == [shard_rows(H, rank, world)]
+        ok &= torch.equal(frame["image"], want["image"]) and torch.equal(frame["depth"], want["depth"])
+        # through the sweep entry point: fewer views than ranks -> every view is rendered by all ranks in row strips
+        out = render_views_sharded(lambda i: (_ for _ in ()).throw(AssertionError("whole-view path taken")), 1,
+                                   render_view_rows=lambda i, rows: _fake_rows(i, rows), H=H)
+        ok &= out["image"].shape == (1, H, 6, 3) and torch.equal(out["depth"][0], _fake_rows(0, list(range(H)))["depth"])
+        # an empty sweep: nothing rendered, no collective entered, on every rank
+        ok &= render_views_sharded(lambda i: {}, 0) == {}
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [40, 21, 5])     # 5 rows on 2 ranks: one 8-row strip -> rank 1 owns no row and still enters the collectives
+def test_one_frame_in_row_strips_two_ranks(H):
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_rows_worker, args=(world, _free_port(), H, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_row_strips_partition_every_row_once():
+    from nerfsafetyvalidation_amd.dist import shard_rows
+    for H, world in ((800, 8), (400, 3), (13, 4)):
+        rows = sorted(r for k in range(world) for r in shard_rows(H, k, world))
+        assert rows == list(range(H))

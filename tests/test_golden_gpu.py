@@ -279,7 +279,8 @@ def test_ffmlp_backbone_golden(device):
     assert rgb_masked.dtype == torch.float32 and not got_m[~f["mask"]].any() and not rgb_none.any()        # zeros where not asked (network_ff.py:108-113)
     np.testing.assert_allclose(got_m[f["mask"]], f["rgb_masked"][f["mask"]], rtol=0, atol=3e-3)
     # the fused encode + MLP kernel on the same points
-    fs, fc = net.fused_model().network_forward(x, d)
+    from helpers import fused16
+    fs, fc = fused16(net).network_forward(x, d)
     np.testing.assert_allclose(fs.cpu().numpy(), f["fwd_sigma"], rtol=1e-2, atol=1e-3)
     np.testing.assert_allclose(fc.cpu().numpy(), f["fwd_rgb"].astype(np.float32), rtol=0, atol=3e-3)
     # one eval frame through run_cuda: operator loop and fused loop

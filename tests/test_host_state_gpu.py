@@ -132,7 +132,8 @@ def test_two_models_run_path_and_network_forward_concurrently(device):
         return o["image"].clone(), o["depth"].clone(), o["sigmas"].clone()
 
     def net_fwd(i):
-        s, c = models[i].fused_model().network_forward(pts, dirs)
+        with torch.autocast("cuda", dtype=torch.float16):
+            s, c = models[i].fused_model().network_forward(pts, dirs)
         return s.clone(), c.clone()
 
     serial = [run_path(0), run_path(1), net_fwd(0), net_fwd(1)]

@@ -33,12 +33,27 @@ def _same_bits(a, b):
     return torch.equal(a, b)
 
 
-# fp16 parity bounds of the composited pixels against the oracle: TWICE what this build was observed to reach on these views
-# (MI355X; printed by the tests), not a generous constant -- a regression in the fused path's numerics shows up here first
-# observed (64x64, views 7 / 160): operators max 5.2e-5 mean 6.9e-8, depth 4.2e-7; fused max 8.0e-5 mean 4.6e-6, depth 9.2e-6
-OBS_MAX_RGB = {False: 1.1e-4, True: 1.6e-4}
-OBS_MEAN_RGB = {False: 1.4e-7, True: 9.2e-6}
-OBS_MAX_DEPTH = {False: 8.4e-7, True: 1.9e-5}
+# fp16 parity bounds: TWICE what this build was observed to reach (MI355X; the tests print the observed values), not generous
+# constants -- a regression in the fused path's numerics shows up here first.  All with the default corner arithmetic of the fused
+# gather (model.fused_reference_rounding = True: c10::Half product and running sum per corner, features bit-identical to grid_encode's).
+# Composited pixels against the oracle (64x64, views 7 / 160): operators max 5.2e-5 mean 6.9e-8, depth 4.2e-7; fused max 5.2e-5 mean
+# 6.8e-8, depth 4.2e-7 -- the same.  (fused_reference_rounding = False, fp32 corner accumulation: 8.0e-5 / 4.6e-6 / 9.2e-6.)
+OBS_MAX_RGB = {False: 1.1e-4, True: 1.1e-4}
+OBS_MEAN_RGB = {False: 1.4e-7, True: 1.4e-7}
+OBS_MAX_DEPTH = {False: 8.4e-7, True: 8.4e-7}
+# Fused vs this package's own operator loop on the same GPU, (max, mean) of |d image|: observed 3.1e-5 / 1.8e-8 (view 33); nn.Linear
+# backbone 1.1e-5 / 1.6e-9 -- the two paths share every feature bit and differ in the MLPs' fp32 summation order only.
+# (With fused_reference_rounding = False the same comparisons gave 2.4e-3 / 9e-5.)
+TOL_FUSED_VS_OPS = (6.2e-5, 3.7e-8)
+TOL_LINEAR_VS_OPS = (2.3e-5, 3.2e-9)
+# (bound, cone stepping, jitter, step budget) -> 2 x observed (rgb max, rgb mean, depth max, depth mean); floors 1e-6 / 1e-8 where less was observed
+TOL_CONFIGS = {(1, False, False, 1024): (5.2e-5, 2.8e-8, 6.7e-6, 1e-8), (2, True, False, 1024): (2.4e-4, 5.9e-8, 1e-6, 1e-8),
+               (2, False, True, 1024): (2.5e-5, 1e-8, 1e-6, 1e-8), (1, True, True, 512): (1e-6, 1e-8, 1e-6, 1e-8),
+               (2, False, False, 100): (4.1e-4, 4.3e-8, 5.2e-6, 1e-8), (4, False, False, 1024): (5.5e-5, 3.7e-8, 2e-6, 1e-8)}
+# Every 97th ray of the 800x800 frames against the oracle, 2 x observed (rays with the oracle's sample sequence: max 3.6e-5 / 6.7e-5, mean
+# 1.6e-7 / 6.2e-8; no ray of the 6598 had another sequence -- the bench line's 320 k rays hold 16, i.e. 0.33 expected here -- and the bench
+# bounds their error at 1e-3)
+TOL_FULL_FRAME = {2: dict(same_max=7.3e-5, same_mean=3.3e-7, n_diff=2, diff_max=2e-3), 1: dict(same_max=1e-4, same_mean=1.3e-7, n_diff=2, diff_max=2e-3)}
 
 
 @pytest.fixture(scope="module")
@@ -79,7 +94,7 @@ def test_network_forward_fused(setup, device, M):
     sc, model, net = setup
     xyz, d = _points(sc, M, seed=M)
     want_s, want_c = net.forward(xyz, d)
-    fm = model.fused_model()
+    fm = Hh.fused16(model)
     s, c = fm.network_forward(_t(xyz, device), _t(d, device))
     np.testing.assert_allclose(s.cpu().numpy(), want_s, rtol=1e-2, atol=1e-3)
     np.testing.assert_allclose(c.cpu().numpy(), want_c.astype(np.float32), rtol=0, atol=3e-3)
@@ -127,6 +142,37 @@ def test_run_cuda_against_oracle(setup, device, view):
         assert out["sigmas"].shape[0] % 128 == 0 and out["rgbs"].shape == (out["sigmas"].shape[0], 3)
 
 
+def test_fused_corner_rounding_modes(setup, device):
+    """model.fused_reference_rounding: True (default) interpolates the hash-grid corners as the reference does (c10::Half product and
+    running sum, NGP_PREC_F16_REF), False accumulates them in fp32 and rounds once (NGP_PREC_F16).  Both against the oracle on one view;
+    the switch takes effect on the next render (the snapshot is rebuilt) and does not leak."""
+    from nerfsafetyvalidation_amd import _lib
+    sc, model, net = setup
+    view = 7
+    ro, rd = Hh.pinhole_rays(sc.poses[view], sc.intrinsics, sc.H, sc.W)
+    want = Hh.oracle_run_cuda(net, ro, rd, sc.bitfield(), sc.bound, sc.cascade, sc.density_scale)
+    want_img = want["image"] + (1 - want["weights_sum"])[:, None] * 1.0
+    assert model.fused_reference_rounding is True
+    errs, imgs = {}, {}
+    try:
+        for mode in (True, False, True):
+            model.fused_reference_rounding = mode
+            _, _, out, _ = _render(model, sc, view, device, True)
+            fm = Hh.fused16(model)
+            assert fm.ref_rounding is mode and fm._struct(None).precision == (_lib.NGP_PREC_F16_REF if mode else _lib.NGP_PREC_F16)
+            img = out["image"].float().cpu().numpy().reshape(-1, 3)
+            if mode in imgs:
+                assert np.array_equal(imgs[mode], img)                 # back to the first mode: the same bits again
+            imgs[mode], errs[mode] = img, np.abs(img - want_img)
+    finally:
+        model.fused_reference_rounding = True
+    print(f"OBS corner rounding modes, view {view}: reference max {errs[True].max():.3e} mean {errs[True].mean():.3e}; "
+          f"fp32 accumulation max {errs[False].max():.3e} mean {errs[False].mean():.3e}")
+    assert not np.array_equal(imgs[True], imgs[False])
+    assert errs[True].max() < OBS_MAX_RGB[True] and errs[True].mean() < OBS_MEAN_RGB[True]
+    assert errs[False].max() < 1.6e-4 and errs[False].mean() < 9.2e-6      # 2 x observed (8.0e-5 / 4.6e-6)
+
+
 def test_fused_equals_operator_loop_exactly_on_march(setup, device):
     """Same GPU, fused vs operator-by-operator loop: identical schedule; images agree to fp16-MLP noise."""
     sc, model, _ = setup
@@ -135,7 +181,8 @@ def test_fused_equals_operator_loop_exactly_on_march(setup, device):
     assert abs(sa["iterations"] - sb["iterations"]) <= 1
     assert abs(sa["samples_slots"] - sb["samples_slots"]) <= 0.002 * sa["samples_slots"]
     d = (a["image"].float() - b["image"].float()).abs()
-    assert d.max().item() < 4e-3 and d.mean().item() < 2e-4
+    print(f"OBS fused vs operator loop (view 33): max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    assert d.max().item() < TOL_FUSED_VS_OPS[0] and d.mean().item() < TOL_FUSED_VS_OPS[1]
     # last-iteration tensors have the reference's padded shape in both paths
     assert a["sigmas"].shape[0] % 128 == 0 and b["sigmas"].shape[0] % 128 == 0
     # ... and the same contents in the reference's row order (the fused path regroups its alive list internally and restores
@@ -151,7 +198,7 @@ def test_fused_equals_operator_loop_exactly_on_march(setup, device):
 def test_fused_handles_edge_cases(setup, device):
     sc, model, _ = setup
     model.fused = True
-    fm = model.fused_model()
+    fm = Hh.fused16(model)
     # all rays miss the box: zero iterations of real work, white image
     ro = np.tile(np.array([[5.0, 5.0, 5.0]], np.float32), (300, 1))
     rd = np.tile(np.array([[0.0, 1.0, 0.0]], np.float32), (300, 1))
@@ -247,9 +294,13 @@ def test_fused_vs_operator_loop_across_configurations(device, bound, dt_gamma, p
     assert abs(sa["iterations"] - sb["iterations"]) <= 1
     assert abs(sa["samples_slots"] - sb["samples_slots"]) <= 0.004 * sa["samples_slots"] + 16
     d = (ia - ib).abs()
-    assert d.max().item() < 6e-3 and d.mean().item() < 3e-4, (d.max().item(), d.mean().item())
     dd = (da - db).abs()
-    assert dd.max().item() < 2e-2 and dd.mean().item() < 5e-4, (dd.max().item(), dd.mean().item())
+    dd = dd[~torch.isnan(dd)]
+    print(f"OBS fused vs operator loop (bound {bound}, dt_gamma {dt_gamma}, perturb {perturb}, {n_rays} rays, {max_steps} steps): "
+          f"rgb max {d.max().item():.3e} mean {d.mean().item():.3e}; depth max {dd.max().item():.3e} mean {dd.mean().item():.3e}")
+    tol = TOL_CONFIGS[(bound, dt_gamma > 0, perturb, max_steps)]
+    assert d.max().item() < tol[0] and d.mean().item() < tol[1], (d.max().item(), d.mean().item())
+    assert dd.max().item() < tol[2] and dd.mean().item() < tol[3], (dd.max().item(), dd.mean().item())
 
 
 def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
@@ -293,7 +344,8 @@ def test_linear_backbone_fused_vs_operator_loop(device):
         b = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False)
         sb = dict(model.last_render_stats)
     d = (a["image"].float() - b["image"].float()).abs()
-    assert d.max().item() < 6e-3 and d.mean().item() < 3e-4, (d.max().item(), d.mean().item())
+    print(f"OBS linear backbone, fused vs operator loop: max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    assert d.max().item() < TOL_LINEAR_VS_OPS[0] and d.mean().item() < TOL_LINEAR_VS_OPS[1], (d.max().item(), d.mean().item())
     assert abs(sa["iterations"] - sb["iterations"]) <= 2
 
 
@@ -638,14 +690,14 @@ def test_full_size_frame_properties(device, bound, radius, view):
     print(f"full-size frame bound {bound} r {radius}: {st_full['samples_marched']} samples, {st_full['iterations']} reference iterations in "
           f"{st_full['launches']} launches ({st_full['replayed']} rolled back)")
     # (a') the per-cell corner records (copies of table entries, one 32-byte record per cell) against plain gathers
-    assert model.fused_model()._cell_levels >= 4
+    assert Hh.fused16(model)._cell_levels >= 4
     model2 = sc.build_model(device)
     model2.fused_cell_table_gb = 0
     keep = model
     model = model2
     nocell, h_nocell, st_nocell = render(0, frame_width=sc.W)
     model = keep
-    assert model2.fused_model()._cell_levels == 0
+    assert Hh.fused16(model2)._cell_levels == 0
     for key in ("image", "depth", "sigmas", "rgbs"):
         assert _same_bits(full[key], nocell[key]), key
     assert _same_bits(h_full, h_nocell) and st_full["samples_marched"] == st_nocell["samples_marched"]
@@ -674,12 +726,19 @@ def test_full_size_frame_properties(device, bound, radius, view):
     want = Hh.oracle_run_cuda(net, np.ascontiguousarray(ro[sel]), np.ascontiguousarray(rd[sel]), sc.bitfield(), sc.bound, sc.cascade,
                               sc.density_scale)
     want_img = want["image"] + (1 - want["weights_sum"])[:, None] * 1.0
-    err = np.abs(img.cpu().numpy()[sel] - want_img)
-    print(f"full-size frame bound {bound}: every 97th ray vs oracle: max |dRGB| {err.max():.2e} mean {err.mean():.2e}")
-    # observed: 9.9e-4 max (a handful of rays whose last sample sits within fp16 noise of the T < 1e-4 stop), 3.2e-6 mean -> 2 x
-    assert err.max() < 2e-3 and err.mean() < 1e-5, (err.max(), err.mean())
+    err = np.abs(img.cpu().numpy()[sel] - want_img).max(axis=1)
     same = h_full.cpu().numpy().view(np.uint32)[sel] == want["sample_hash"]
-    assert same.mean() > 0.995, same.mean()
+    n_diff = int((~same).sum())
+    print(f"OBS full-size frame bound {bound}: every 97th ray ({sel.size}) vs oracle: rays with the oracle's sample sequence: max |dRGB| "
+          f"{err[same].max():.3e} mean {err[same].mean():.3e}; {n_diff} rays with another sequence, max |dRGB| {err[~same].max() if n_diff else 0:.3e}")
+    # Rays are split by whether their sample sequence (hash of every (dt, delta) bit pattern) is the oracle's.  On those the image
+    # differs by the fp16 network's arithmetic only: north-star 1e-4.  A ray with another sequence took one sample more or fewer --
+    # its transmittance crossed the T < 1e-4 stop (raymarching.cu:890) within fp16 noise of the threshold: counted and bounded apart.
+    tol = TOL_FULL_FRAME[bound]
+    assert err[same].max() <= tol["same_max"] and err[same].mean() <= tol["same_mean"], (err[same].max(), err[same].mean())
+    assert n_diff <= tol["n_diff"], n_diff
+    if n_diff:
+        assert err[~same].max() <= tol["diff_max"], err[~same].max()
     missed = want["nears"] >= want["fars"]
     if missed.any():
         assert np.all(img.cpu().numpy()[sel][missed] == 1.0)
@@ -779,7 +838,7 @@ def test_run_path_and_network_forward_with_and_without_cell_records(device):
             r = model.render(_t(ro, device)[None], _t(rd, device)[None], staged=True, max_ray_batch=4096, bg_color=1, perturb=False,
                              num_steps=128, upsample_steps=0)
             sg, rgb = model.fused_model().network_forward(_t(xyz, device), _t(d, device))
-        assert model.fused_model()._cell_levels == (12 if gb else 0)
+        assert Hh.fused16(model)._cell_levels == (12 if gb else 0)
         outs.append((r["image"].float().clone(), r["depth"].float().clone(), r["aggregated_density"].float().clone(), sg.clone(), rgb.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
@@ -931,7 +990,7 @@ def test_fused_gather_vs_grid_encode_operator(device):
     from nerfsafetyvalidation_amd import _lib
     sc = _scene(H=16, W=16)
     model = sc.build_model(device)
-    fm = model.fused_model()
+    fm = Hh.fused16(model)
     fm._ensure_cells()
     assert fm._cell_levels == 12
     rng = np.random.default_rng(3)
