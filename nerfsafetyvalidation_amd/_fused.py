@@ -102,6 +102,8 @@ class FusedModel:
         self.cascade, self.grid_size = net.cascade, net.grid_size
         self._watched = watched
         self._snapshot = _versions(watched)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()   # the blobs were cast / padded on the building thread's stream; other streams render with them next
         self._ctxs = {}          # one render context per host thread: [handle, capacity] (frames may be in flight on several streams)
         self._ctx_lock = threading.Lock()
         self._pad = None
@@ -188,6 +190,8 @@ class FusedModel:
     def _ensure_cells(self):
         """Expand the first twelve levels when the budget and a third of the free device memory allow (gridencoder.grid.DerivedTables)."""
         self._ensure_packed()
+        if self._tables is not None:
+            self._tables.table_for_current_stream()        # (this thread's stream reads the shared fp16 copy / records from now on)
         if self._cells_ready:
             return
         if self.cell_table_gb > 0 and not self.f32:

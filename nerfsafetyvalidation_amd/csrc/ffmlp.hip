@@ -302,7 +302,7 @@ static int ffmlp_run(const uint16_t* inputs, const uint16_t* weights, uint32_t B
                      uint16_t* outputs, hipStream_t s, const char* what) {
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && weights && outputs, "%s: null pointer", what);
-    NGP_REQUIRE(B % 16 == 0, "%s: batch size must be a multiple of 16 (got %u); the FFMLP wrapper pads to 128", what, B);
+    NGP_REQUIRE(B % 16 == 0, "%s: batch size must be a multiple of 16 (got %u); the FFMLP wrapper pads a ragged tail to 16", what, B);
     NGP_REQUIRE(input_dim > 0 && input_dim % 16 == 0, "FFMLP input_dim should be 16 * m (m > 0), but got %u", input_dim);
     NGP_REQUIRE(output_dim == 16, "FFMLP current only supports (padded) output dim == 16, but got %u", output_dim);
     NGP_REQUIRE(num_layers >= 2, "FFMLP num_layers should be larger than 2 (3 matmuls), but got %u", num_layers);
@@ -903,8 +903,19 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
                        uint16_t* grad_weights, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
     (void)output_activation;  // not transferred by the reference either (ffmlp.cu:462-464); FFMLP always passes `none`
-    if (B == 0) return NGP_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        // an empty batch (a training step whose march found no sample): no row contributes, so the weight gradient is exactly zero --
+        // the caller's buffer is uninitialised memory that autograd would otherwise accumulate into weights.grad
+        if (grad_weights) {
+            const size_t n = (size_t)hidden_dim * (input_dim + (size_t)hidden_dim * (num_layers - 1) + output_dim);
+            if (hipMemsetAsync(grad_weights, 0, n * sizeof(uint16_t), s) != hipSuccess) {
+                set_error("ffmlp_backward: %s", hipGetErrorString(hipGetLastError()));
+                return NGP_ELAUNCH;
+            }
+        }
+        return NGP_OK;
+    }
     NGP_REQUIRE(grad && inputs && weights && forward_buffer && grad_weights, "ffmlp_backward: null pointer");
     NGP_REQUIRE(!calc_grad_inputs || grad_inputs, "ffmlp_backward: calc_grad_inputs without a grad_inputs buffer");
     NGP_REQUIRE(B % 16 == 0, "ffmlp_backward: batch size must be a multiple of 16 (got %u)", B);

@@ -2116,6 +2116,10 @@ struct RenderArgs {
     uint32_t block_jump;              // LIN kernels: leave empty 4x4x4 blocks in one step (Dda::jump_block)
     uint32_t* sample_hash;            // diagnostics (ngp_debug_set_sample_hash): per-ray FNV hash of the marched (dt, delta1) bit patterns
     unsigned long long* stamps;       // diagnostics only (ngp_debug_set_stamps): per-phase cycle sums; NULL in normal runs
+    // what k_march_ahead leaves for k_render_iter: the (t, dt) of every sample of this launch, [chunk][sample][lane] (a wave's 64 rays of one
+    // sample index are 512 contiguous bytes), and per list entry the number of samples marched (bits 0-5) + the slow-ray flag (bit 7)
+    float2* march_samples;
+    uint8_t* march_counts;
 };
 
 struct WaveSlab {  // per-wave LDS: kCh march steps of 64 rays
@@ -2138,8 +2142,67 @@ __device__ __forceinline__ void dump_row(const RenderArgs& ra, uint32_t entry, i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The occupancy-grid march of one launch, on its own (raymarching.cu:757-813 for every live ray, all of the launch's samples).
+// It used to run inside k_render_iter's waves, lane = ray, in lock-step: a third of the wave time at a lane utilisation of 0.44, in
+// waves that hold the MLPs' 128 registers (4 per SIMD).  A ray's sample sequence does not depend on the network -- only on where
+// compositing stops it -- so the march of ALL samples a launch may need is taken out: one lane per ray in small, register-light
+// waves (full occupancy hides the probe latency chain), results through a [chunk][sample][lane] buffer that the network waves read
+// back as whole lines.  Samples of rays that stop early are marched for nothing (the reference marches them too: march_rays runs
+// n_step samples for every alive ray before composite_rays looks at any).  The sequence is the one k_render_iter produced: same
+// Dda, same restart of the march at the iteration boundaries of a multi-iteration launch (from the re-accumulated rays_t), same jitter.
 // LIN: power-of-two grid with the linear copies of the occupancy bits (Dda::probe_lin); otherwise the Morton-order originals
-template <int MODE, bool LIN, bool HACC = false>
+// ------------------------------------------------------------------------------------------
+template <bool LIN>
+__global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound) {
+    const Ctl ctl = *ra.ctl;
+    if (ctl.done) return;
+    const uint32_t n_alive = ctl.n_alive, n_step = ctl.n_step, spec = ctl.spec;
+    __shared__ uint32_t coarse_lds[kCoarseMaxBytes / 4];
+    for (uint32_t i = threadIdx.x; i < ra.coarse_words; i += blockDim.x) coarse_lds[i] = ra.coarse[i];
+    __syncthreads();
+    const uint32_t* coarse = ra.coarse_words ? coarse_lds : nullptr;
+    const uint32_t entry = blockIdx.x * blockDim.x + threadIdx.x;
+    if (entry >= n_alive) return;
+    const int32_t ray = ra.alive_in[entry];
+    Dda dda;
+    dda.init(ra.rays_o + (size_t)ray * 3, ra.rays_d + (size_t)ray * 3, ra.bitfield, bound, ra.dt_gamma, ra.max_steps, ra.cascade, ra.grid_size);
+    if (LIN) dda.init_lin(ra.bitfield_lin, ra.log_grid, ra.block_jump != 0);
+    const float t_c = ra.rays_t[ray], far = ra.fars[ray];
+    float t_march = t_c;
+    if (ra.perturb) {
+        Pcg32 rng = ra.rng;
+        rng.advance((int64_t)entry);
+        t_march += dda.dt_min * rng.next_float();
+    }
+    float last_m = t_march;              // the march's last_t (:727-731)
+    float geo_tc = t_c;                  // rays_t as composite_rays re-accumulates it (:848): where the next iteration's march restarts
+    uint32_t emitted = 0;
+    float2* out = ra.march_samples + ((size_t)(entry >> 6) * n_step) * 64 + (entry & 63u);
+    float x, y, z, dt;
+    while (t_march < far && emitted < n_step) {
+        if (LIN ? dda.probe_lin(t_march, x, y, z, dt, coarse) : dda.probe(t_march, x, y, z, dt, coarse)) {
+            out[(size_t)emitted * 64] = make_float2(t_march, dt);
+            t_march += dt;
+            const float d1 = t_march - last_m;   // deltas[1] of this sample (:791-793)
+            last_m = t_march;
+            geo_tc += d1;
+            emitted++;
+            if (spec && emitted % spec == 0) {   // iteration boundary inside the launch: march_rays starts again from rays_t with last_t = t
+                t_march = geo_tc;
+                last_m = geo_tc;
+            }
+        }
+    }
+    // Rays whose next march begins inside an empty 4x4x4 block are about to skip through empty space (tens of DDA probes) while the
+    // others take one probe per sample: k_render_iter groups them into their own chunks (a scheduling decision only).  The flag is
+    // meaningful for rays that complete all n_step samples -- the survivors -- whose rays_t then is geo_tc.
+    bool slow = false;
+    if (ra.sort_slow && emitted == n_step) slow = geo_tc < far && (LIN ? dda.coarse_empty_at_lin(geo_tc, coarse) : dda.coarse_empty_at(geo_tc, coarse));
+    ra.march_counts[entry] = (uint8_t)(emitted | (slow ? 128u : 0u));
+}
+
+template <int MODE, bool HACC = false>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
@@ -2152,9 +2215,6 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
     WaveSlab* slabs = reinterpret_cast<WaveSlab*>(smem + w_bytes + sizeof(LevelTab));
-    uint32_t* coarse_lds = reinterpret_cast<uint32_t*>(smem + w_bytes + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab));
-    for (uint32_t i = threadIdx.x; i < ra.coarse_words; i += blockDim.x) coarse_lds[i] = ra.coarse[i];
-    const uint32_t* coarse = ra.coarse_words ? coarse_lds : nullptr;
     stage_block(na, lv, Wlds, lt, w_bytes);   // the only workgroup barrier: waves are independent from here on
 
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15;
@@ -2189,36 +2249,34 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         const bool active = entry < n_alive;
         const int32_t ray = active ? ra.alive_in[entry] : -1;
 
-        Dda dda;
-        float t_march = 0, last_t = 0, t_c = 0, far = 0;
+        float last_t = 0, t_c = 0, t_c0 = 0, t_start = 0;
         float ws = 0, dep = 0, cr = 0, cg = 0, cb = 0;
+        uint32_t emitted = 0;                // samples k_march_ahead marched for this lane's ray in this launch
+        bool slow_next = false;              // ... and whether the ray's next march starts in an empty 4x4x4 block (if it survives)
         if (active) {
-            dda.init(ra.rays_o + (size_t)ray * 3, ra.rays_d + (size_t)ray * 3, ra.bitfield, na.bound, ra.dt_gamma, ra.max_steps, ra.cascade,
-                     ra.grid_size);
-            if (LIN) dda.init_lin(ra.bitfield_lin, ra.log_grid, ra.block_jump != 0);
             t_c = ra.rays_t[ray];      // composite_rays' t (:848) accumulates from the unperturbed value
-            far = ra.fars[ray];
-            t_march = t_c;
-            if (ra.perturb) {
+            t_c0 = t_c;
+            t_start = t_c;
+            if (ra.perturb) {          // where the march started: the first sample's deltas[1] counts from here (:727-731)
+                const float SQRT3 = 1.7320508075688772f;
                 Pcg32 rng = ra.rng;
                 rng.advance((int64_t)entry);
-                t_march += dda.dt_min * rng.next_float();
+                t_start += (2 * SQRT3 / (float)ra.max_steps) * rng.next_float();
             }
-            last_t = t_march;
+            last_t = t_start;
+            const uint32_t mc = ra.march_counts[entry];
+            emitted = mc & 63u;
+            slow_next = (mc & 128u) != 0;
             ws = ra.weights_sum[ray]; dep = ra.depth[ray];
             cr = ra.image[(size_t)ray * 3]; cg = ra.image[(size_t)ray * 3 + 1]; cb = ra.image[(size_t)ray * 3 + 2];
-            S.od[lane][0] = dda.ox; S.od[lane][1] = dda.oy; S.od[lane][2] = dda.oz;
-            S.od[lane][3] = dda.dx; S.od[lane][4] = dda.dy; S.od[lane][5] = dda.dz;
+#pragma unroll
+            for (int d = 0; d < 3; d++) { S.od[lane][d] = ra.rays_o[(size_t)ray * 3 + d]; S.od[lane][3 + d] = ra.rays_d[(size_t)ray * 3 + d]; }
             if (spec) {   // the state this launch starts from, should its verification fail (k_render_compact restores it)
                 ra.backup[(size_t)ray * 2] = make_float4(t_c, ws, dep, ra.sample_hash ? __uint_as_float(ra.sample_hash[ray]) : 0.0f);
                 ra.backup[(size_t)ray * 2 + 1] = make_float4(cr, cg, cb, 0.0f);
             }
         }
-        float last_m = last_t;               // march-side copy of last_t
-        float geo_tc = t_c;                  // march-side copy of rays_t across the iteration boundaries of a speculative launch
-        uint32_t emitted = 0;                // samples marched by this lane in this launch
-        uint32_t hsh = 0;
-        if (active && ra.sample_hash) hsh = ra.sample_hash[ray];
+        const float2* marched = ra.march_samples + ((size_t)chunk * n_step) * 64 + lane;
         // ray states: running -> (terminated by T < 1e-4 | exhausted: the march ran out of samples) -> dead
         bool running = active;
         uint32_t steps_done = 0;      // samples composited so far (== n_step at the end <=> the ray survives)
@@ -2228,41 +2286,17 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             const uint32_t want = (n_step - s0) < (uint32_t)kCh ? (n_step - s0) : (uint32_t)kCh;
             // ---- 1. march (raymarching.cu:757-813), lane = ray.  A ray whose compositing already stopped is not marched
             //         further unless the caller asked for the reference's last-iteration tensors.
-            uint32_t cnt = 0, n_probes = 0;
+            uint32_t cnt = 0;
             // (a launch that covers several iterations is never the reference's last one: nothing of it is dumped)
             const bool do_march = active && (running || (ra.last_sigmas != nullptr && !spec));
-            if (do_march) {
-                float x, y, z, dt;
-                while (t_march < far && cnt < want) {
-                    n_probes++;
-                    if (LIN ? dda.probe_lin(t_march, x, y, z, dt, coarse) : dda.probe(t_march, x, y, z, dt, coarse)) {
-                        S.t[lane * kCh + cnt] = t_march;
-                        S.dt[lane * kCh + cnt] = dt;
-                        t_march += dt;
-                        const float d1 = t_march - last_m;   // deltas[1] of this sample (:791-793)
-                        last_m = t_march;
-                        if (ra.sample_hash) {
-                            hsh = (hsh ^ __float_as_uint(dt)) * 16777619u;
-                            hsh = (hsh ^ __float_as_uint(d1)) * 16777619u;
-                        }
-                        if (spec) {
-                            // composite_rays accumulates rays_t += deltas[1] per sample (:848); at an iteration boundary the next
-                            // march_rays starts from that value with last_t = t (:727-731)
-                            geo_tc += d1;
-                            if (++emitted % spec == 0) {
-                                t_march = geo_tc;
-                                last_m = geo_tc;
-                            }
-                        }
-                        cnt++;
-                    }
+            if (do_march) {      // this sub-pass's samples, as k_march_ahead left them
+                const uint32_t left = emitted > s0 ? emitted - s0 : 0u;
+                cnt = left < want ? left : want;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const float2 v = marched[(size_t)(s0 + k) * 64];
+                    S.t[lane * kCh + k] = v.x;
+                    S.dt[lane * kCh + k] = v.y;
                 }
-            }
-            if (ra.stamps) {   // diagnostics: lane utilisation of the march (sum and per-wave max of DDA probes)
-                uint32_t mx = n_probes, sm = n_probes;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64)); sm += __shfl_xor(sm, off, 64); }
-                if (lane == 0) { atomicAdd(ra.stamps + 4, (unsigned long long)mx); atomicAdd(ra.stamps + 5, (unsigned long long)sm); atomicAdd(ra.stamps + 6, 1ull); }
             }
             if (!__any(cnt != 0)) {
                 // nothing to evaluate in this sub-pass for the whole wave
@@ -2282,7 +2316,6 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
             }
             const uint32_t total = __shfl(incl, 63, 64);
             for (uint32_t k = 0; k < cnt; k++) S.list[incl - cnt + k] = (uint16_t)((lane << 3) | k);
-            wave_samples += total;
             const uint32_t n_tiles = (total + 15) / 16;
             unsigned long long sub_a = 0, sub_b = 0, sub_n = 0, sub_f = 0;   // diagnostics only
             uint32_t pre[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // MODE 2: the lane's hashed-level entries, gathered a tile ahead
@@ -2389,7 +2422,24 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         const bool survive = active && running && steps_done == n_step;
         if (active) {
             if (survive) ra.rays_t[ray] = t_c;
-            if (ra.sample_hash) ra.sample_hash[ray] = hsh;
+            if (ra.sample_hash) {
+                // diagnostics: FNV hash of the (dt, deltas[1]) bit patterns of the samples the reference marches for this ray in this
+                // launch -- all n_step of every iteration it enters alive, composited or not (march_rays runs before composite_rays)
+                const uint32_t entered = (spec && !survive) ? (steps_done / spec + 1) * spec : n_step;
+                const uint32_t n_hash = emitted < entered ? emitted : entered;
+                uint32_t hsh = ra.sample_hash[ray];
+                float lm = t_start, gtc = t_c0;       // the march's last_t and the re-accumulated rays_t, as k_march_ahead carries them
+                for (uint32_t i = 0; i < n_hash; i++) {
+                    const float2 v = marched[(size_t)i * 64];
+                    const float ta = v.x + v.y, d1 = ta - lm;
+                    lm = ta;
+                    hsh = (hsh ^ __float_as_uint(v.y)) * 16777619u;
+                    hsh = (hsh ^ __float_as_uint(d1)) * 16777619u;
+                    gtc += d1;
+                    if (spec && (i + 1) % spec == 0) lm = gtc;
+                }
+                ra.sample_hash[ray] = hsh;
+            }
             ra.weights_sum[ray] = ws; ra.depth[ray] = dep;
             ra.image[(size_t)ray * 3] = cr; ra.image[(size_t)ray * 3 + 1] = cg; ra.image[(size_t)ray * 3 + 2] = cb;
         }
@@ -2397,8 +2447,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         // probes) while the others take one probe per sample.  Grouping them into their own chunks keeps the lanes of a
         // wave doing comparable work (measured lane utilisation of the march without this: 19 %).  The order of the alive
         // list does not enter any result (perturb == 0), so this is a pure scheduling decision.
-        bool slow = false;
-        if (ra.sort_slow && survive) slow = t_c < far && (LIN ? dda.coarse_empty_at_lin(t_c, coarse) : dda.coarse_empty_at(t_c, coarse));
+        const bool slow = ra.sort_slow && survive && slow_next;      // (k_march_ahead looked the ray's next start position up)
         const unsigned long long ball_f = __ballot(survive && !slow), ball_s = __ballot(survive && slow);
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         if (survive && !slow) ra.staging[(size_t)chunk * 64 + (uint32_t)__popcll(ball_f & lt_mask)] = ray;
@@ -2406,16 +2455,16 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         if (lane == 0) ra.chunk_count[chunk] = (uint32_t)__popcll(ball_f) | ((uint32_t)__popcll(ball_s) << 16);
         if (spec) {
             // a ray that completed m samples died in the launch's m-th iteration: the n_alive sequence follows from these counts.
-            // The samples the reference marches are those of the iterations the ray entered alive (march-ahead within a sub-pass
-            // may have produced one more).
             const uint32_t ds = ((blockIdx.x * kWaves + wid) % kDeathShards) * kSpecK;
             for (uint32_t m = 0; m < n_step / spec; m++) {
                 const uint32_t cdead = (uint32_t)__popcll(__ballot(active && !survive && steps_done / spec == m));
                 if (lane == 0 && cdead) atomicAdd(&ra.death_shards[ds + m], cdead);
             }
+        }
+        {
             // samples the reference marches for this ray: all of every iteration it enters alive (march_rays runs before
-            // composite_rays); a ray that completed steps_done samples entered iterations 0 .. steps_done / spec
-            const uint32_t entered = survive ? n_step : (steps_done / spec + 1) * spec;
+            // composite_rays); in a multi-iteration launch a ray that completed steps_done samples entered iterations 0 .. steps_done / spec
+            const uint32_t entered = (spec && !survive) ? (steps_done / spec + 1) * spec : n_step;
             uint32_t rm = active ? (emitted < entered ? emitted : entered) : 0u;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) rm += __shfl_xor(rm, off, 64);
@@ -2761,6 +2810,8 @@ struct ngp_render_ctx {
     uint32_t* grid_lin = nullptr;           // x-fastest copy of the occupancy bitfield (k_build_linear), allocated on first use
     uint32_t* death_shards = nullptr;       // [kDeathShards][kSpecK] per-iteration death counts of a speculative launch
     float4* backup = nullptr;               // [max_rays][2] per-ray state a speculative launch starts from (for its rollback)
+    float2* march_samples = nullptr;        // [(max_rays + 64) * 8] (t, dt) of the current launch's samples (k_march_ahead -> k_render_iter)
+    uint8_t* march_counts = nullptr;        // [max_rays] samples marched per list entry + slow-ray flag
     float4* dump_rec = nullptr;             // lazily allocated: [max_rays][8]
     uint32_t* dump_iter = nullptr;          // [max_rays]
     Ctl* ctl = nullptr;          // device [2]
@@ -2946,6 +2997,9 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
     ok &= hipMalloc(&c->death_shards, 2 * (size_t)kDeathShards * kSpecK * sizeof(uint32_t)) == hipSuccess;   // two buffers, by launch parity
     ok &= hipMalloc(&c->backup, (size_t)max_rays * 2 * sizeof(float4)) == hipSuccess;
+    // (n_alive * n_step <= 8 N in every regime of the schedule: n_step <= 8 while more than N / 5 rays live, <= 32 below that)
+    ok &= hipMalloc(&c->march_samples, ((size_t)max_rays + 64) * 8 * sizeof(float2)) == hipSuccess;
+    ok &= hipMalloc(&c->march_counts, (size_t)max_rays) == hipSuccess;
     ok &= hipMalloc(&c->heads, 2 * sizeof(QueueHeads)) == hipSuccess;
     ok &= hipMalloc(&c->packed, (size_t)(sig_halfs(2) + sig_halfs(3)) * 2) == hipSuccess;
     ok &= hipHostMalloc(&c->status, kRing * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -2975,7 +3029,7 @@ int ngp_render_ctx_set_frame_width(ngp_render_ctx* ctx, uint32_t width) {
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
-    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->death_shards); (void)hipFree(c->backup); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
+    (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->death_shards); (void)hipFree(c->backup); (void)hipFree(c->march_samples); (void)hipFree(c->march_counts); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -3028,6 +3082,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
     ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count; ra.stat_shards = ctx->stat_shards;
     ra.backup = ctx->backup;
+    ra.march_samples = ctx->march_samples; ra.march_counts = ctx->march_counts;
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
@@ -3076,19 +3131,16 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.dump_rec = ctx->dump_rec;
         ra.dump_iter = ctx->dump_iter;
     }
-    const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab) + (use_coarse ? coarse_bytes : 0);
+    const size_t lds = weights_bytes(na) + sizeof(LevelTab) + (size_t)kWaves * sizeof(WaveSlab);
     const uint32_t blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
     const bool generic = needs_generic(lv);
     const bool use_cells = na.cells != nullptr;
-    // the kernel instantiation of this call: (index recipe) x (occupancy bit layout) x (corner rounding)
+    // the kernel instantiation of this call: (index recipe) x (corner rounding)
     typedef void (*IterKernel)(NetArgs, GridLevels, RenderArgs);
     const int mode = generic ? 1 : (use_cells ? 2 : 0);
-    static const IterKernel kIter[2][2][3] = {
-        {{k_render_iter<0, false, false>, k_render_iter<1, false, false>, k_render_iter<2, false, false>},
-         {k_render_iter<0, true, false>, k_render_iter<1, true, false>, k_render_iter<2, true, false>}},
-        {{k_render_iter<0, false, true>, k_render_iter<1, false, true>, k_render_iter<2, false, true>},
-         {k_render_iter<0, true, true>, k_render_iter<1, true, true>, k_render_iter<2, true, true>}}};
-    const IterKernel iter_kernel = kIter[na.hacc() ? 1 : 0][lin ? 1 : 0][mode];
+    static const IterKernel kIter[2][3] = {{k_render_iter<0, false>, k_render_iter<1, false>, k_render_iter<2, false>},
+                                           {k_render_iter<0, true>, k_render_iter<1, true>, k_render_iter<2, true>}};
+    const IterKernel iter_kernel = kIter[na.hacc() ? 1 : 0][mode];
     ensure_dynamic_lds(reinterpret_cast<const void*>(iter_kernel), 160 * 1024);
     NGP_REQUIRE(lds <= 160 * 1024, "render_rays: LDS budget exceeded (%zu bytes)", lds);
 
@@ -3108,7 +3160,12 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.heads = ctx->heads + cur;
         ra.death_shards = ctx->death_shards + (size_t)cur * kDeathShards * kSpecK;
         {
-            ProfScope pk("k_render_iter", s, 0);  // per-launch events only when ngp_prof_enable(1)
+            ProfScope pm("k_march_ahead", s, 0);  // per-launch events only when ngp_prof_enable(1)
+            if (lin) k_march_ahead<true><<<div_up(ub ? ub : 1, 256), 256, 0, s>>>(ra, na.bound);
+            else k_march_ahead<false><<<div_up(ub ? ub : 1, 256), 256, 0, s>>>(ra, na.bound);
+        }
+        {
+            ProfScope pk("k_render_iter", s, 0);
             iter_kernel<<<blocks, kThreads, lds, s>>>(na, lv, ra);
         }
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
@@ -3118,7 +3175,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
                                                            ctx->backup, ctx->rays_t, weights_sum, depth, image, dbg.sample_hash, ctx->stat_shards,
                                                            ctx->death_shards + (size_t)(cur ^ 1) * kDeathShards * kSpecK);
         launched++;
-        launches += 2;
+        launches += 3;
         // consume every status that has already landed; block only when too far ahead
         while (known < launched) {
             const bool must_wait = launched - known >= (uint32_t)kLookahead;

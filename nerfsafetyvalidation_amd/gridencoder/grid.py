@@ -34,10 +34,30 @@ class DerivedTables:
     def __init__(self, param):
         self.key = (param.data_ptr(), param._version, param.device)
         self.emb16 = param.detach().to(torch.half).contiguous()
+        self._streams = set()
+        if self.emb16.is_cuda:
+            # converted on the building thread's stream; other threads' streams launch readers of it next (pipeline.FramePipeline)
+            cur = torch.cuda.current_stream(self.emb16.device)
+            cur.synchronize()
+            self._streams.add(cur.cuda_stream)
         self.seen = 1
         self.points = 0                       # points encoded with this version of the table (operator calls)
         self.cells, self.cell_levels, self.cells_tried = None, 0, False
         self.lock = threading.Lock()
+
+    def table_for_current_stream(self):
+        """the fp16 copy, marked as in use by the calling thread's stream (once per stream): when this entry is replaced -- the
+        parameter moved on -- its memory goes back to the allocator only after the work queued on every consumer stream has run"""
+        if self.emb16.is_cuda:
+            cur = torch.cuda.current_stream(self.emb16.device)
+            if cur.cuda_stream not in self._streams:
+                with self.lock:
+                    if cur.cuda_stream not in self._streams:
+                        self.emb16.record_stream(cur)
+                        if self.cells is not None:
+                            self.cells.record_stream(cur)
+                        self._streams.add(cur.cuda_stream)
+        return self.emb16
 
     def ensure_cells(self, offsets_host, S, H_base, gridtype, align_corners, budget_gb=None):
         """build the per-cell records of the first twelve levels if they fit the budget (GB; default NGP_CELL_TABLE_GB or 48, and a
@@ -60,6 +80,9 @@ class DerivedTables:
                 cells = torch.empty(nbytes, dtype=torch.uint8, device=self.emb16.device)
                 _lib.check(lib.ngp_build_cell_tables(C.byref(m), 12, _lib.ptr(cells), _lib.stream()), "build_cell_tables")
                 torch.cuda.current_stream(self.emb16.device).synchronize()   # other streams may read it next
+                for sid in self._streams:                                    # (streams that already use the table will read the records too)
+                    if sid != torch.cuda.current_stream(self.emb16.device).cuda_stream:
+                        cells.record_stream(torch.cuda.ExternalStream(sid, device=self.emb16.device))
                 self.cells, self.cell_levels = cells, 12
             self.cells_tried = True
         return self.cells, self.cell_levels
@@ -114,7 +137,7 @@ class _grid_encode(Function):
         if torch.is_autocast_enabled("cuda") and C % 2 == 0:
             if embeddings.dtype == torch.float32 and isinstance(embeddings, nn.Parameter):
                 ent = derived_tables(embeddings)
-                embeddings = ent.emb16
+                embeddings = ent.table_for_current_stream()
                 # the records take ~9 ms to build and save ~30 % of a forward: worth it once this version of the table has encoded
                 # tens of millions of points (a frame rendered operator by operator), not for the few chunks of a density-grid
                 # update between two optimiser steps

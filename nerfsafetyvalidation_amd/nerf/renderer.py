@@ -340,9 +340,11 @@ class NeRFRenderer(nn.Module):
         """the fused kernel clips sample positions to [-bound, bound]^3; a user-edited aabb takes the operator path"""
         aabb = self.aabb_train if self.training else self.aabb_infer
         key = (aabb.data_ptr(), aabb._version)
-        if getattr(self, "_aabb_key", None) != key:
-            self._aabb_key, self._aabb_cube = key, aabb.tolist() == [-self.bound] * 3 + [self.bound] * 3
-        return self._aabb_cube
+        cached = getattr(self, "_aabb_cube_cache", None)       # ONE attribute, read once: frames are rendered from several threads
+        if cached is None or cached[0] != key:
+            cached = (key, aabb.tolist() == [-self.bound] * 3 + [self.bound] * 3)      # (one device read per version of the buffer)
+            self._aabb_cube_cache = cached
+        return cached[1]
 
     def _render_staged_fused(self, fm, rays_o, rays_d, max_ray_batch, num_steps=128, upsample_steps=0, bg_color=None, **kwargs):
         """staged render through `run` for the whole frame in ONE fused launch (ngp_render_uniform); same result dict as the chunk

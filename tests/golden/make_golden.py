@@ -659,9 +659,5 @@ if __name__ == "__main__":
     gen_sh_literal()
     gen_density_grid()
     gen_background()
-    # keep the reference tree pristine
-    import shutil
-    for dirpath, dirnames, _ in os.walk(REF):
-        for d in list(dirnames):
-            if d == "__pycache__":
-                shutil.rmtree(os.path.join(dirpath, d), ignore_errors=True)
+    # (sys.dont_write_bytecode is set at the top: importing the reference creates nothing under its tree, and this script never
+    #  writes or deletes there)
