@@ -53,11 +53,20 @@ def _rays_kernel(poses, intrinsics, H, W, inds):
     return _RaysKernel.apply(poses, intrinsics, H, W, inds)
 
 
-@torch.amp.autocast("cuda", enabled=False)
 def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None):
     """poses [B,4,4] cam2world, intrinsics (fx,fy,cx,cy) -> {'rays_o','rays_d' [B,N,3], ('inds' [B,N])}.
 
-    `inds` (extension): explicit flat pixel ids [n] shared by all cameras; generates only those rays."""
+    `inds` (extension): explicit flat pixel ids [n] shared by all cameras; generates only those rays.
+
+    Runs with autocast disabled, as the reference's decorator does (nerf/utils.py:52).  A context manager per CALL, not the
+    decorator: `@torch.autocast(...)` wraps every call in ONE shared context object whose saved `prev` state the threads of a frame
+    pipeline overwrite for each other -- a thread inside its own autocast block then leaves get_rays with autocast switched off
+    (found by scripts/fuzz_training.py: the viewer thread's next render raised in the FFMLP)."""
+    with torch.autocast("cuda", enabled=False):
+        return _get_rays(poses, intrinsics, H, W, N, error_map, inds)
+
+
+def _get_rays(poses, intrinsics, H, W, N, error_map, inds):
     device = poses.device
     B = poses.shape[0]
     results = {}

@@ -369,6 +369,29 @@ def gen_run_grad():
          **{f"g_{k}": v for k, v in _grads(net).items()}, **_weights(net))
 
 
+def gen_density_grad():
+    """The trajectory planner's query (nav/quad_plot.py:223-249 through validate.py:283-288): density_fn = model.density(x.reshape(-1, 3)
+    @ rot)['sigma'] on the body points of every planned state, squared into the collision cost, backward to the points.  fp32, no
+    autocast (the planner runs outside any), and a table with full fp32 draws -- NOT representable in fp16."""
+    bound = 2
+    torch.manual_seed(5)
+    net = RefNetwork(encoding="hashgrid", bound=bound, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1)
+    g = torch.Generator().manual_seed(3)
+    net.encoder.embeddings.data.copy_(torch.rand(net.encoder.embeddings.shape, generator=g) - 0.5)
+    net = net.eval()
+    for p_ in net.parameters():
+        p_.requires_grad_(False)                # a frozen map: the planner optimises the states only
+    rot = torch.tensor([[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]])       # validate.py:283 (Blender -> NeRF axes)
+    x = ((torch.rand(12, 50, 3, generator=g) * 2 - 1) * 0.9).requires_grad_(True)     # [states, body points, 3]
+    sigma = net.density(x.reshape((-1, 3)) @ rot)["sigma"].reshape(x.shape[:-1])       # validate.py:288 density_fn
+    w = torch.rand(12, 50, generator=g)
+    cost = (sigma ** 2 * w).sum()                # quad_plot.py:232-241: density ** 2 weighted along the trajectory
+    cost.backward()
+    geo = net.density(x.detach().reshape((-1, 3)) @ rot)["geo_feat"]
+    save("density_grad.npz", bound=bound, table_seed=3, rot=rot.numpy(), x=x.detach().numpy(), w=w.numpy(), sigma=sigma.detach().numpy(),
+         geo_feat=geo.detach().numpy(), cost=float(cost), grad_x=x.grad.numpy(), **_weights(net))
+
+
 def _grads(net):
     return {f"sigma{i}": l.weight.grad.numpy() for i, l in enumerate(net.sigma_net)} | {
         f"color{i}": l.weight.grad.numpy() for i, l in enumerate(net.color_net)}
@@ -645,6 +668,11 @@ def gen_state_dict_keys():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                        # python make_golden.py density_grad [...]: only the named fixtures
+        for name in sys.argv[1:]:
+            globals()[f"gen_{name}"]()
+        sys.exit(0)
+    gen_density_grad()
     gen_get_rays()
     gen_grid_wrapper()
     gen_sh_wrapper()

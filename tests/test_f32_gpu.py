@@ -305,3 +305,39 @@ def test_ffmlp_backbone_outside_autocast_raises_like_the_reference(device):
             m.fused = False
             ops = m.render(rot, rdt, staged=True, bg_color=1, perturb=False, num_steps=32, upsample_steps=0)
     assert np.abs(out["image"].float().cpu().numpy() - ops["image"].float().cpu().numpy()).max() < 2e-3
+
+
+def test_planner_density_query_against_the_reference_fixture(device):
+    """density_grad.npz: the reference's NeRFNetwork.density driven on CPU (fp32, oracle encoders) exactly as validate.py:283-288's
+    density_fn calls it -- body points @ rot, ['sigma'], reshape -- squared into a cost and differentiated to the points
+    (nav/quad_plot.py:223-249).  This package's model under the same closure: fused fp32 forward + backward, and the operators."""
+    from nerfsafetyvalidation_amd.nerf.network import NeRFNetwork
+    f = np.load(os.path.join(G, "density_grad.npz"), allow_pickle=False)
+    net = NeRFNetwork(encoding="hashgrid", bound=int(f["bound"]), cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1)
+    g = torch.Generator().manual_seed(int(f["table_seed"]))
+    net.encoder.embeddings.data.copy_(torch.rand(net.encoder.embeddings.shape, generator=g) - 0.5)
+    for i, l in enumerate(net.sigma_net):
+        l.weight.data.copy_(torch.from_numpy(f[f"sigma{i}"]))
+    for i, l in enumerate(net.color_net):
+        l.weight.data.copy_(torch.from_numpy(f[f"color{i}"]))
+    net = net.to(device).eval()
+    net.requires_grad_(False)
+    rot = torch.from_numpy(f["rot"]).to(device)
+    density_fn = lambda x: net.density(x.reshape((-1, 3)) @ rot)["sigma"].reshape(x.shape[:-1])   # noqa: E731  (validate.py:288)
+    w = torch.from_numpy(f["w"]).to(device)
+    for fused in (True, False):
+        net.fused = fused
+        x = torch.from_numpy(f["x"]).to(device).requires_grad_(True)
+        sigma = density_fn(x)
+        cost = (sigma ** 2 * w).sum()
+        cost.backward()
+        np.testing.assert_allclose(sigma.detach().cpu().numpy(), f["sigma"], rtol=2e-5, atol=1e-6)
+        assert abs(float(cost) - float(f["cost"])) <= 2e-5 * abs(float(f["cost"]))
+        scale = np.abs(f["grad_x"]).max()
+        err = np.abs(x.grad.cpu().numpy() - f["grad_x"]).max() / scale
+        print(f"planner query vs the reference fixture (fused={fused}): max |d grad| / max |grad| = {err:.2e}")
+        assert err <= 1e-4
+        geo = net.density(x.detach().reshape((-1, 3)) @ rot)["geo_feat"]
+        np.testing.assert_allclose(geo.cpu().numpy(), f["geo_feat"], rtol=0, atol=2e-5)
+    net.fused = True
+    assert net._fused_cache32 is not None
