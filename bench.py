@@ -317,7 +317,10 @@ def rollout_main(args):
             "frames_per_sec": round(frames / elapsed, 3), "simulator_steps_per_sec": round(frames / 2 / elapsed, 3),
             "nominal_samples_per_sec": round(nominal / elapsed, 1), "evaluated_fraction": round(evaluated_fraction, 5) if evaluated_fraction else None,
             "roofline": roof, "cpu_baseline": cpu, "host": host_facts(),
-            "rows": int(rows.shape[0]), "mean_sigma_d_opt": float(rows[:, 21].mean()), "collisions": int(rows[:, 22].sum())}))
+            "rows": int(rows.shape[0]), "median_sigma_d_opt": float(np.median(rows[:, 21])), "mean_sigma_d_opt": float(rows[:, 21].mean()),
+            "sigma_d_opt_note": "where scipy's BFGS stops on the reference's objective, which has no minimum in sigma_d (DESIGN.md section 5): a run that "
+                                "wanders off shows in the mean, the reward clips it (NerfSimulator.py:171-181)",
+            "collisions": int(rows[:, 22].sum())}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -608,6 +611,8 @@ def parity_against_oracle(np, torch, lib, model, sc, poses, intr, H, W, view, st
                 sub_o, sub_d = rays0["rays_o"][:, ::stride].contiguous(), rays0["rays_d"][:, ::stride].contiguous()
                 out0 = model.render(sub_o, sub_d, staged=True, bg_color=1, perturb=False)
                 torch.cuda.synchronize()
+                hashes = hbuf[:sub_o.shape[1]].cpu().numpy().view(np.uint32).copy()
+                lib.ngp_debug_set_sample_hash(None)
                 # (rate of the mode: the whole frame, after the call above rebuilt the model's snapshot if the mode changed)
                 model.render(rays0["rays_o"], rays0["rays_d"], staged=True, bg_color=1, perturb=False, frame_width=W)
                 torch.cuda.synchronize()
@@ -624,7 +629,7 @@ def parity_against_oracle(np, torch, lib, model, sc, poses, intr, H, W, view, st
         want_img = res["image"] + (1.0 - res["weights_sum"])[:, None]
         err = np.abs(got_img - want_img).max(axis=1)
         mse = float(np.mean((got_img - want_img) ** 2))
-        same = hbuf.cpu().numpy().view(np.uint32)[:got_img.shape[0]] == res["sample_hash"]
+        same = hashes == res["sample_hash"]
         hit = res["nears"] < res["fars"]
         got_dep = out0["depth"].float().cpu().numpy()[0]
         want_dep = np.where(hit, np.clip(res["depth"] - res["nears"], 0, None) / np.where(hit, res["fars"] - res["nears"], 1), 0)
