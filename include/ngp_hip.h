@@ -123,6 +123,21 @@ NGP_API int ngp_grid_encode_backward(const void* grad, const float* inputs, cons
                              uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
                              void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, void* workspace,
                              size_t workspace_bytes, ngp_stream_t stream);
+/* The same two operators with the position of a (level, point) feature group in outputs / grad given by the caller, in elements:
+ * element (level, b, c) is at level * level_stride + b * point_stride + c.  (B * C, C) is the operator's [L,B,C]; (Bp * C, C) is level
+ * planes with a padded row count Bp >= B -- what ngp_ffmlp_forward_planes / _backward_planes read and write in place, so that the
+ * permute + copy of gridencoder/grid.py:52 and :72 (64 B read + 64 B written per point, each way) disappears; (C, L * C) is the
+ * module's [B, L*C].  Same kernels, same arithmetic, same values; rows or planes the call does not address are left untouched. */
+NGP_API int ngp_grid_encode_forward_strided(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                    int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                                    const void* cell_tables, uint32_t cell_levels, uint32_t level_stride, uint32_t point_stride,
+                                    ngp_stream_t stream);
+NGP_API int ngp_grid_encode_backward_strided(const void* grad, const float* inputs, const void* embeddings,
+                                     const int32_t* offsets_host, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                     uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void* dy_dx,
+                                     void* grad_inputs, uint32_t gridtype, int align_corners, int dtype, void* workspace,
+                                     size_t workspace_bytes, uint32_t level_stride, uint32_t point_stride, ngp_stream_t stream);
 /* The table gradient of large fp16 two-feature batches is a binned two-pass scatter through a CALLER-OWNED device workspace
  * (nothing is kept between calls, so calls on different streams are independent).  ngp_grid_encode_backward_workspace returns
  * the size that lets all levels go through the bins (0: this shape does not use one).  A smaller workspace makes the call process
@@ -138,6 +153,22 @@ NGP_API int ngp_sh_encode_forward(const float* inputs, float* outputs, uint32_t 
 NGP_API int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, ngp_stream_t stream);
 
+/* ---------------- the elementwise steps between the two FFMLPs (nerf/network_ff.py:55-70) ----------------
+ * What the reference's NeRFNetwork.forward does in torch between sigma_net and color_net, and after color_net, as one kernel each way
+ * (values identical to the torch chain; host-side convenience of this build, the reference has no native entry for it):
+ *   sigma [B] f32 = exp(float(h[:,0]))  (activation.py:8-12);  color_input [B_pad,32] f16 = [ half(SH_4(dirs)) | h[:,1:16] | 0 ]
+ *   (network_ff.py:66-69), rows B..B_pad-1 zero (the FFMLP's row padding, ffmlp.py:156-158).  h [>=B,16] f16, dirs [B,3] f32.
+ * backward: grad_h [B_pad,16] f16 from grad_sigma [B] f32 (activation.py:14-17) and grad_color_input [>=B,32] f16 (either may be NULL). */
+NGP_API int ngp_ff_sigma_color_input(const uint16_t* h, const float* dirs, uint32_t B, uint32_t B_pad, float* sigma, uint16_t* color_input,
+                             ngp_stream_t stream);
+NGP_API int ngp_ff_sigma_color_input_backward(const uint16_t* h, const float* grad_sigma, const uint16_t* grad_color_input, uint32_t B,
+                                      uint32_t B_pad, uint16_t* grad_h, ngp_stream_t stream);
+/* rgb [B,3] f16 = sigmoid(outputs16[:, :3]) (network_ff.py:70,98: torch.sigmoid of the colour FFMLP's padded 16-wide output);
+ * backward: grad_outputs16 [B_pad,16] f16, columns 3..15 and rows >= B zero. */
+NGP_API int ngp_ff_rgb(const uint16_t* outputs16, uint32_t B, uint16_t* rgb, ngp_stream_t stream);
+NGP_API int ngp_ff_rgb_backward(const uint16_t* grad_rgb, const uint16_t* rgb, uint32_t B, uint32_t B_pad, uint16_t* grad_outputs16,
+                        ngp_stream_t stream);
+
 /* ---------------- _ffmlp (ffmlp/src/ffmlp.h:8-15) ---------------- */
 
 /* ffmlp.cu:636-709.  fp16 only.  inputs [B,input_dim], B % 16 == 0 (the wrapper pads to 128);
@@ -147,6 +178,17 @@ NGP_API int ngp_sh_encode_backward(const float* grad, const float* inputs, uint3
 NGP_API int ngp_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                       uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs, ngp_stream_t stream);
+/* (this build) ngp_ffmlp_forward / ngp_ffmlp_backward with the INPUT side in the hash-grid operator's level-major layout: inputs and
+ * grad_inputs are [input_dim/2][B][2] (gridencoder.cu's [L,B,C], C == 2, B rows per plane) instead of [B,input_dim].  64-wide networks
+ * (input_dim % 32 == 0, 2-4 layers); forward_buffer NULL = inference.  Everything else as the plain calls. */
+NGP_API int ngp_ffmlp_forward_planes(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
+                             uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                             uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs, ngp_stream_t stream);
+NGP_API int ngp_ffmlp_backward_planes(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer,
+                              uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                              uint32_t activation, uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
+                              uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
+                              ngp_stream_t stream);
 NGP_API int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,

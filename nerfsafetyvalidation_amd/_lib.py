@@ -60,12 +60,22 @@ SIGNATURES = {
     "ngp_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int, _int, _vp, _u32, _vp],
     "ngp_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _u32, _int,
                                  _int, _vp, _sz, _vp],
+    "ngp_grid_encode_forward_strided": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int, _int, _vp, _u32,
+                                        _u32, _u32, _vp],
+    "ngp_grid_encode_backward_strided": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _u32, _int,
+                                         _int, _vp, _sz, _u32, _u32, _vp],
     "ngp_grid_encode_backward_workspace": [_u32, _u32, _u32, _u32, _int],
     "ngp_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _int, _vp, _vp],
     "ngp_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp],
+    "ngp_ff_sigma_color_input": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
+    "ngp_ff_sigma_color_input_backward": [_vp, _vp, _vp, _u32, _u32, _vp, _vp],
+    "ngp_ff_rgb": [_vp, _u32, _vp, _vp],
+    "ngp_ff_rgb_backward": [_vp, _vp, _u32, _u32, _vp, _vp],
     "ngp_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "ngp_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "ngp_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp, _vp, _sz, _vp],
+    "ngp_ffmlp_forward_planes": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "ngp_ffmlp_backward_planes": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp, _vp, _sz, _vp],
     "ngp_ffmlp_backward_workspace": [_u32, _u32, _u32, _u32],
     "ngp_ffmlp_backward_buffer_bytes": [_u32, _u32, _u32, _u32],
     "ngp_ffmlp_allocate_splitk": [_sz],

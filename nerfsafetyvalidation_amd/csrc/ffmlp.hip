@@ -75,6 +75,32 @@ __device__ __forceinline__ half4 act_output(uint32_t act, const f32x4& acc) {
 __device__ __forceinline__ half4 ld_half4(const _Float16* p) { return *reinterpret_cast<const half4*>(p); }
 __device__ __forceinline__ void st_half4(_Float16* p, half4 v) { *reinterpret_cast<half4*>(p) = v; }
 
+// Four consecutive input columns col .. col + 3 (col % 4 == 0) of a row.  PLANES: the input side is in the hash-grid operator's
+// level-major layout [input_dim / 2][B][2] (gridencoder.cu's [L,B,C] with C == 2) -- columns 2l, 2l + 1 of row b are the pair at
+// (l * B + b) -- so the encoder's output and the gradient handed back to it are read and written where they lie, without the
+// module's permute + copy each way (grid.py:52,72).  A 16-lane row group reads / writes 64 contiguous bytes per pair.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <bool PLANES>
+__device__ __forceinline__ half4 ld_in4(const _Float16* in, size_t row, uint32_t col, uint32_t in_dim, uint32_t B) {
+    if constexpr (!PLANES) {
+        return ld_half4(in + row * in_dim + col);
+    } else {
+        const _Float16* p = in + ((size_t)(col >> 1) * B + row) * 2;
+        const half2v a = *reinterpret_cast<const half2v*>(p), b = *reinterpret_cast<const half2v*>(p + (size_t)B * 2);
+        return (half4){a[0], a[1], b[0], b[1]};
+    }
+}
+template <bool PLANES>
+__device__ __forceinline__ void st_in4(_Float16* out, size_t row, uint32_t col, uint32_t in_dim, uint32_t B, half4 v) {
+    if constexpr (!PLANES) {
+        st_half4(out + row * in_dim + col, v);
+    } else {
+        _Float16* p = out + ((size_t)(col >> 1) * B + row) * 2;
+        *reinterpret_cast<half2v*>(p) = (half2v){v[0], v[1]};
+        *reinterpret_cast<half2v*>(p + (size_t)B * 2) = (half2v){v[2], v[3]};
+    }
+}
+
 // HB = hidden_dim / 16
 template <int HB>
 __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restrict__ inputs, const _Float16* __restrict__ weights,
@@ -167,7 +193,7 @@ static size_t ffmlp_lds_halves(uint32_t in_dim, uint32_t hid, uint32_t num_layer
     return (size_t)hid * (in_dim + 8) + (size_t)(num_layers - 1) * hid * (hid + 8) + (size_t)16 * (hid + 8);
 }
 
-template <int HB, int R, bool RELU>
+template <int HB, int R, bool RELU, bool PLANES = false>
 __global__ void __launch_bounds__(256) k_ffmlp_forward_lds(const _Float16* __restrict__ inputs, const _Float16* __restrict__ weights,
                                                            uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t activation,
                                                            uint32_t output_activation, _Float16* __restrict__ fwd_buf,
@@ -205,8 +231,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward_lds(const _Float16* __res
             half8v xb[R];
 #pragma unroll
             for (int t = 0; t < R; t++) {
-                const _Float16* p = inputs + (size_t)row[t] * in_dim + kb * 32 + q * 4;
-                xb[t] = live[t] ? cat8(ld_half4(p), ld_half4(p + 16)) : (half8v){0, 0, 0, 0, 0, 0, 0, 0};
+                xb[t] = live[t] ? cat8(ld_in4<PLANES>(inputs, row[t], kb * 32 + q * 4, in_dim, B), ld_in4<PLANES>(inputs, row[t], kb * 32 + q * 4 + 16, in_dim, B))
+                                : (half8v){0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
             for (int ob = 0; ob < HB; ob++) {
@@ -270,20 +296,20 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward_lds(const _Float16* __res
 
 constexpr size_t kFfmlpLdsMax = 64 * 1024;   // two workgroups per CU
 
-template <int HB, int R>
+template <int HB, int R, bool PLANES = false>
 static void launch_ffmlp_lds(const uint16_t* in, const uint16_t* w, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                              uint32_t out_act, uint16_t* fwd, uint16_t* out, hipStream_t s) {
     const size_t lds = ffmlp_lds_halves(in_dim, HB * 16, num_layers) * sizeof(_Float16);
-    ensure_dynamic_lds((const void*)k_ffmlp_forward_lds<HB, R, true>, (int)kFfmlpLdsMax);
-    ensure_dynamic_lds((const void*)k_ffmlp_forward_lds<HB, R, false>, (int)kFfmlpLdsMax);
+    ensure_dynamic_lds((const void*)k_ffmlp_forward_lds<HB, R, true, PLANES>, (int)kFfmlpLdsMax);
+    ensure_dynamic_lds((const void*)k_ffmlp_forward_lds<HB, R, false, PLANES>, (int)kFfmlpLdsMax);
     const uint32_t n_groups = div_up(B / 16, (uint32_t)R);
     uint32_t blocks = div_up(n_groups, 4);
     if (blocks > 256 * 2) blocks = 256 * 2;   // two resident workgroups per CU, grid-stride beyond that
     if (act == 0)
-        k_ffmlp_forward_lds<HB, R, true><<<blocks, 256, lds, s>>>((const _Float16*)in, (const _Float16*)w, B, in_dim, num_layers, act, out_act,
+        k_ffmlp_forward_lds<HB, R, true, PLANES><<<blocks, 256, lds, s>>>((const _Float16*)in, (const _Float16*)w, B, in_dim, num_layers, act, out_act,
                                                                    (_Float16*)fwd, (_Float16*)out);
     else
-        k_ffmlp_forward_lds<HB, R, false><<<blocks, 256, lds, s>>>((const _Float16*)in, (const _Float16*)w, B, in_dim, num_layers, act, out_act,
+        k_ffmlp_forward_lds<HB, R, false, PLANES><<<blocks, 256, lds, s>>>((const _Float16*)in, (const _Float16*)w, B, in_dim, num_layers, act, out_act,
                                                                     (_Float16*)fwd, (_Float16*)out);
 }
 
@@ -299,7 +325,7 @@ static void launch_ffmlp(const uint16_t* in, const uint16_t* w, uint32_t B, uint
 
 static int ffmlp_run(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation, uint16_t* fwd,
-                     uint16_t* outputs, hipStream_t s, const char* what) {
+                     uint16_t* outputs, hipStream_t s, const char* what, bool planes = false) {
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && weights && outputs, "%s: null pointer", what);
     NGP_REQUIRE(B % 16 == 0, "%s: batch size must be a multiple of 16 (got %u); the FFMLP wrapper pads a ragged tail to 16", what, B);
@@ -307,6 +333,13 @@ static int ffmlp_run(const uint16_t* inputs, const uint16_t* weights, uint32_t B
     NGP_REQUIRE(output_dim == 16, "FFMLP current only supports (padded) output dim == 16, but got %u", output_dim);
     NGP_REQUIRE(num_layers >= 2, "FFMLP num_layers should be larger than 2 (3 matmuls), but got %u", num_layers);
     ProfScope prof("ffmlp_forward", s, B);
+    if (planes) {
+        NGP_REQUIRE(hidden_dim == 64 && input_dim % 32 == 0 && ffmlp_lds_halves(input_dim, 64, num_layers) * sizeof(_Float16) <= kFfmlpLdsMax,
+                    "%s: the level-major input layout is built for the 64-wide networks with input_dim %% 32 == 0 (got hidden %u, input %u, layers %u)",
+                    what, hidden_dim, input_dim, num_layers);
+        launch_ffmlp_lds<4, 4, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s);
+        return check_launch(what);
+    }
     if ((hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128) && input_dim % 32 == 0 &&
         ffmlp_lds_halves(input_dim, hidden_dim, num_layers) * sizeof(_Float16) <= kFfmlpLdsMax) {
         switch (hidden_dim) {
@@ -375,6 +408,16 @@ __device__ __forceinline__ half4 transfer_pack(uint32_t act, const f32x4& acc, h
 #pragma unroll
     for (int r = 0; r < 4; r++) h[r] = act_transfer(act, (_Float16)acc[r], f[r]);
     return h;
+}
+
+// RELU: the activation is known to be ReLU at compile time (every network on the path); otherwise any code, out of line.  With the
+// runtime switch inlined at each of its 96 sites the fused kernel spent most of its issue slots on scalar compare-and-branch chains
+// (1.26 G VALU + as many scalar instructions per launch against 0.12 G MFMAs: profiles/r02_pmc_round2_kernels.json).
+__device__ __attribute__((noinline)) half4 transfer_pack_call(uint32_t act, f32x4 acc, half4 f) { return transfer_pack(act, acc, f); }
+template <bool RELU>
+__device__ __forceinline__ half4 transfer_pack_t(uint32_t act, const f32x4& acc, half4 f) {
+    if constexpr (RELU) return transfer_pack(0u, acc, f);
+    else return transfer_pack_call(act, acc, f);
 }
 
 __host__ __device__ __forceinline__ uint32_t lds_stride(uint32_t cols) { return cols + (cols == 16 ? 0u : 16u); }
@@ -525,7 +568,7 @@ constexpr uint32_t kFusedTPW = 2, kFusedRows = 4 * kFusedTPW * 16;
 __device__ __forceinline__ half8v tr_pair(const _Float16* p, uint32_t stride16) {   // two 16-row tiles, k = 0..31
     return cat8(lds_tr_read(p), lds_tr_read(p + stride16));
 }
-template <int NL>
+template <int NL, bool PLANES = false, bool RELU = false>
 __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
                                                          const _Float16* __restrict__ weights, const _Float16* __restrict__ fwd, uint32_t B,
                                                          uint32_t in_dim, uint32_t act, _Float16* __restrict__ bwd,
@@ -578,7 +621,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
 #pragma unroll
                 for (int ib = 0; ib < HB; ib++) fa[l][t][ib] = ld_half4(fwd + (size_t)l * BH + row[t] * HID + ib * 16 + g * 4);
 #pragma unroll
-            for (int ib = 0; ib < HB; ib++) xin[t][ib] = ib < (int)IB ? ld_half4(inputs + row[t] * in_dim + ib * 16 + g * 4) : zero4;
+            for (int ib = 0; ib < HB; ib++) xin[t][ib] = ib < (int)IB ? ld_in4<PLANES>(inputs, row[t], ib * 16 + g * 4, in_dim, B) : zero4;
         }
         half4 dh[TPW][HB];
         {
@@ -595,7 +638,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
 #pragma unroll
                 for (int t = 0; t < (int)TPW; t++) {
                     const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, gB[t], (f32x4){0, 0, 0, 0}, 0, 0, 0);
-                    dh[t][ib] = transfer_pack(act, acc, fl[t][ib]);
+                    dh[t][ib] = transfer_pack_t<RELU>(act, acc, fl[t][ib]);
                     if (bwd && valid[t]) st_half4(bwd + row[t] * HID + ib * 16 + g * 4, dh[t][ib]);
                 }
             }
@@ -633,7 +676,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
                 }
 #pragma unroll
                 for (int t = 0; t < (int)TPW; t++) {
-                    dn[t][ib] = transfer_pack(act, acc[t], fm[t][ib]);
+                    dn[t][ib] = transfer_pack_t<RELU>(act, acc[t], fm[t][ib]);
                     if (bwd && valid[t]) st_half4(bwd + (size_t)(k + 1) * BH + row[t] * HID + ib * 16 + g * 4, dn[t][ib]);
                 }
             }
@@ -686,7 +729,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
                     half4 h;
 #pragma unroll
                     for (int r = 0; r < 4; r++) h[r] = (_Float16)acc[t][r];
-                    if (valid[t]) st_half4(grad_inputs + row[t] * in_dim + ib * 16 + g * 4, h);
+                    if (valid[t]) st_in4<PLANES>(grad_inputs, row[t], ib * 16 + g * 4, in_dim, B, h);
                 }
             }
         }
@@ -722,15 +765,22 @@ static bool fused_bwd_applies(uint32_t in_dim, uint32_t hidden_dim, uint32_t num
     static const bool off = getenv("NGP_FFMLP_NO_FUSED_BWD") != nullptr;     // diagnostics: the two-kernel form for every shape
     return !off && hidden_dim == 64 && num_layers >= 2 && num_layers <= 4 && in_dim <= 64;
 }
-template <int NL>
+template <int NL, bool PLANES = false>
 static void launch_bwd_fused(const uint16_t* grad, const uint16_t* inputs, const uint16_t* w, const uint16_t* fwd, uint32_t B, uint32_t in_dim,
                              uint32_t act, uint16_t* bwd, uint16_t* gi, float* ws, uint32_t P, hipStream_t s) {
     const size_t lds = fused_bwd_lds_bytes(in_dim, NL);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(k_ffmlp_bwd_fused<NL>), 160 * 1024);
     const uint32_t n_groups = div_up(B / 16, 4 * kFusedTPW);
-    k_ffmlp_bwd_fused<NL><<<fused_bwd_blocks(B, in_dim, NL), 256, lds, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)w,
-                                                                            (const _Float16*)fwd, B, in_dim, act, (_Float16*)bwd, (_Float16*)gi,
-                                                                            n_groups, ws, P);
+    if (act == 0) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_ffmlp_bwd_fused<NL, PLANES, true>), 160 * 1024);
+        k_ffmlp_bwd_fused<NL, PLANES, true><<<fused_bwd_blocks(B, in_dim, NL), 256, lds, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)w,
+                                                                                              (const _Float16*)fwd, B, in_dim, act, (_Float16*)bwd,
+                                                                                              (_Float16*)gi, n_groups, ws, P);
+    } else {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k_ffmlp_bwd_fused<NL, PLANES, false>), 160 * 1024);
+        k_ffmlp_bwd_fused<NL, PLANES, false><<<fused_bwd_blocks(B, in_dim, NL), 256, lds, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)w,
+                                                                                               (const _Float16*)fwd, B, in_dim, act, (_Float16*)bwd,
+                                                                                               (_Float16*)gi, n_groups, ws, P);
+    }
 }
 
 // One wave per workgroup.  blockIdx.x = batch chunk, blockIdx.y = unit: up to 4x4 output fragments of one matrix.
@@ -898,10 +948,10 @@ int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
                      (hipStream_t)stream, "ffmlp_inference");
 }
 
-int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer, uint32_t B,
-                       uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
-                       uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
-                       uint16_t* grad_weights, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+static int ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer, uint32_t B,
+                          uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                          uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
+                          uint16_t* grad_weights, void* workspace, size_t workspace_bytes, bool planes, ngp_stream_t stream) {
     (void)output_activation;  // not transferred by the reference either (ffmlp.cu:462-464); FFMLP always passes `none`
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) {
@@ -934,6 +984,14 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
     if (fused_bwd_applies(input_dim, hidden_dim, num_layers) &&
         workspace_bytes >= (size_t)fused_bwd_blocks(B, input_dim, num_layers - 1) * P * 4) {
         const uint32_t S = fused_bwd_blocks(B, input_dim, num_layers - 1);
+        if (planes) {
+            NGP_REQUIRE(input_dim % 4 == 0, "ffmlp_backward: the level-major input layout needs input_dim %% 4 == 0");
+            switch (num_layers) {
+                case 2: launch_bwd_fused<1, true>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
+                case 3: launch_bwd_fused<2, true>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
+                default: launch_bwd_fused<3, true>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
+            }
+        } else
         switch (num_layers) {
             case 2: launch_bwd_fused<1>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
             case 3: launch_bwd_fused<2>(grad, inputs, weights, forward_buffer, B, input_dim, activation, backward_buffer, gi, ws, P, s); break;
@@ -944,6 +1002,8 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
         k_ffmlp_bwd_reduce<<<div_up(P, 64), 64 * kReduceWaves, 0, s>>>(ws, S, P, (_Float16*)grad_weights);
         return check_launch("ffmlp_backward (split-K reduction)");
     }
+    NGP_REQUIRE(!planes, "ffmlp_backward: the level-major input layout is built for the 64-wide networks (2-4 layers, input_dim <= 64) with the "
+                         "workspace ngp_ffmlp_backward_workspace() asks for");
     NGP_REQUIRE(backward_buffer, "ffmlp_backward: this shape takes the two-kernel form, which needs backward_buffer");
     uint32_t S;
     const uint32_t chunk = splitk_plan(B, P, workspace_bytes, S);
@@ -964,6 +1024,29 @@ int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
     if (rc) return rc;
     k_ffmlp_bwd_reduce<<<div_up(P, 64), 64 * kReduceWaves, 0, s>>>(ws, S, P, (_Float16*)grad_weights);
     return check_launch("ffmlp_backward (split-K reduction)");
+}
+
+int ngp_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer, uint32_t B,
+                       uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                       uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
+                       uint16_t* grad_weights, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    return ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                          calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, workspace, workspace_bytes, false, stream);
+}
+
+int ngp_ffmlp_forward_planes(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                             uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                             uint16_t* forward_buffer, uint16_t* outputs, ngp_stream_t stream) {
+    return ffmlp_run(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer,
+                     outputs, (hipStream_t)stream, "ffmlp_forward_planes", true);
+}
+
+int ngp_ffmlp_backward_planes(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights, const uint16_t* forward_buffer, uint32_t B,
+                              uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                              uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer, uint16_t* grad_inputs,
+                              uint16_t* grad_weights, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    return ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                          calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, workspace, workspace_bytes, true, stream);
 }
 
 size_t ngp_ffmlp_backward_workspace(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {

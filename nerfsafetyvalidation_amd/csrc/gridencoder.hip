@@ -75,11 +75,19 @@ __device__ __forceinline__ bool decode_block(uint32_t L, uint32_t& level, uint32
     return level < L;
 }
 
+// Where the C features of a (level, point) pair sit in `outputs` / `grad`, in elements.  The reference's operator interface is
+// level-major [L, B, C] (gridencoder.cu:448-478: strides B * C and C); ngp_grid_encode_*_strided take the two strides from the caller
+// -- level planes with padded row counts (what the FFMLP reads in place, ngp_ffmlp_forward_planes) or the module's [B, L*C].
+struct GridIo {
+    uint32_t ls, bs;            // element strides of a level and of a point
+    __host__ __device__ size_t at(uint32_t level, uint32_t b) const { return (size_t)level * ls + (size_t)b * bs; }
+};
+
 // :75-224
 template <typename T, int D, int C, bool GRAD>
 __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __restrict__ inputs, const T* __restrict__ grid,
                                                              T* __restrict__ outputs, uint32_t B, uint32_t L, GridLevels lv,
-                                                             T* __restrict__ dy_dx, uint32_t gridtype, bool align_corners) {
+                                                             T* __restrict__ dy_dx, uint32_t gridtype, bool align_corners, GridIo io) {
     uint32_t level, pb;
     if (!decode_block(L, level, pb)) return;
     const uint32_t b = pb * kGridBlock + threadIdx.x;
@@ -98,7 +106,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
         oob |= (in[d] < 0 || in[d] > 1);
     }
     using V = Vec<T, C>;
-    V* out = reinterpret_cast<V*>(outputs + ((size_t)level * B + b) * C);
+    V* out = reinterpret_cast<V*>(outputs + io.at(level, b));
     T* dydx = GRAD ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : nullptr;
     if (oob) {
         V z;
@@ -184,7 +192,8 @@ template <bool GRAD, bool PAIR>
 __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __restrict__ inputs, const _Float16* __restrict__ grid,
                                                                  _Float16* __restrict__ outputs, uint32_t B, uint32_t L, GridLevels lv,
                                                                  _Float16* __restrict__ dy_dx, uint32_t gridtype, bool align_corners,
-                                                                 const uint4* __restrict__ cells, uint32_t cell_levels, GridLevels cell_off) {
+                                                                 const uint4* __restrict__ cells, uint32_t cell_levels, GridLevels cell_off,
+                                                                 GridIo io) {
     constexpr int D = 3, C = 2;
     constexpr int NL = PAIR ? 2 : 4;                 // levels per lane
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, k = bid >> 3;
@@ -211,7 +220,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
             if (level >= L) break;
             V z;
             z.v[0] = (_Float16)0; z.v[1] = (_Float16)0;
-            *reinterpret_cast<V*>(outputs + ((size_t)level * B + b) * C) = z;
+            *reinterpret_cast<V*>(outputs + io.at(level, b)) = z;
             if (GRAD) {
                 _Float16* dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
 #pragma unroll
@@ -268,7 +277,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
             acc_mul(res.v[0], w, corner[idx].v[0]);
             acc_mul(res.v[1], w, corner[idx].v[1]);
         }
-        *reinterpret_cast<V*>(outputs + ((size_t)level * B + b) * C) = res;
+        *reinterpret_cast<V*>(outputs + io.at(level, b)) = res;
         if (GRAD) {     // :177-222
             const float scale = lv.scale[level];
             _Float16* dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
@@ -372,7 +381,7 @@ __device__ __forceinline__ bool locate(const float* __restrict__ inputs, uint32_
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                               T* __restrict__ grad_grid, uint32_t B, uint32_t L, GridLevels lv,
-                                                              uint32_t gridtype, bool align_corners, BinLevels rest, uint32_t n_rest) {
+                                                              uint32_t gridtype, bool align_corners, BinLevels rest, uint32_t n_rest, GridIo io) {
     // the levels left to this kernel (not LDS-accumulated, not binned), dealt round-robin over the workgroups: atomics execute at
     // the memory side, so there is no L2 affinity to keep and every XCD works on every level
     const uint32_t level = rest.level[blockIdx.x % n_rest], pb = blockIdx.x / n_rest;
@@ -388,7 +397,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restric
     float g[C];
     bool nonzero = false;
     if (valid) {
-        const V gv = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
+        const V gv = *reinterpret_cast<const V*>(grad + io.at(level, b));
 #pragma unroll
         for (int c = 0; c < C; c++) { g[c] = (float)gv.v[c]; nonzero |= g[c] != 0.0f; }
     } else {
@@ -466,7 +475,7 @@ constexpr float kSmallScale = 0x1p30f, kSmallInvScale = 0x1p-30f;
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                                        T* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
-                                                                       bool align_corners, uint32_t small_mask) {
+                                                                       bool align_corners, uint32_t small_mask, GridIo io) {
     extern __shared__ unsigned long long acc[];
     uint32_t level = 0, seen = 0;
     for (uint32_t l = 0; l < (uint32_t)kMaxLevels; l++)
@@ -492,7 +501,7 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
 #pragma unroll
         for (int c = 0; c < C; c++) g[c] = 0.0f;
         if (valid) {
-            const V gv = *reinterpret_cast<const V*>(grad + ((size_t)level * B + b) * C);
+            const V gv = *reinterpret_cast<const V*>(grad + io.at(level, b));
 #pragma unroll
             for (int c = 0; c < C; c++) { g[c] = (float)gv.v[c]; nonzero |= g[c] != 0.0f; }
         }
@@ -606,7 +615,7 @@ constexpr float kMergeScale = 0x1p26f, kMergeInvScale = 0x1p-26f;
 template <int D, int NT, bool MERGE>
 __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs,
                                                      _Float16* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
-                                                     bool align_corners, BinLevels bl, uint32_t first, BinPlan plan) {
+                                                     bool align_corners, BinLevels bl, uint32_t first, BinPlan plan, GridIo io) {
     constexpr int C = 2, NC = 1 << D;
     constexpr uint32_t RC = MERGE ? NT * NC / 2 : NT * NC;          // staged records
     constexpr int TPS = MERGE ? (int)((kMergeSlots + NT - 1) / NT) : 1;     // table slots per thread
@@ -635,7 +644,7 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     bool valid = locate<_Float16, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
     float g[C] = {0.0f, 0.0f};
     if (valid) {
-        const Vec<_Float16, C> gv = *reinterpret_cast<const Vec<_Float16, C>*>(grad + ((size_t)level * B + b) * C);
+        const Vec<_Float16, C> gv = *reinterpret_cast<const Vec<_Float16, C>*>(grad + io.at(level, b));
         g[0] = (float)gv.v[0]; g[1] = (float)gv.v[1];
     }
     // A point whose gradient is zero adds nothing to any entry: it emits no records.  (Not a corner case: the padding rows of a
@@ -887,7 +896,7 @@ static size_t bin_level_bytes(uint32_t B, uint32_t corners) {
 // :317-343
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kGridBlock) k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx,
-                                                                    T* __restrict__ grad_inputs, uint32_t B, uint32_t L) {
+                                                                    T* __restrict__ grad_inputs, uint32_t B, uint32_t L, GridIo io) {
     const uint32_t t = blockIdx.x * kGridBlock + threadIdx.x;
     if (t >= B * D) return;
     const uint32_t b = t / D, d = t - b * D;
@@ -896,7 +905,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_input_backward(const T* __r
     for (uint32_t l = 0; l < L; l++) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const T g = grad[((size_t)l * B + b) * C + c];
+            const T g = grad[io.at(l, b) + c];
             const T x = dd[(size_t)l * D * C + d * C + c];
             if constexpr (sizeof(T) == 4) result = fmaf((float)g, (float)x, (float)result);
             else result = result + (T)(g * x);
@@ -935,23 +944,23 @@ void fill_levels(GridLevels& lv, const int32_t* offsets_host, uint32_t L, float 
 
 template <typename T, int D, int C>
 static void launch_forward(const float* inputs, const void* emb, void* out, uint32_t B, uint32_t L, const GridLevels& lv, bool grad,
-                           void* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+                           void* dy_dx, uint32_t gridtype, bool ac, GridIo io, hipStream_t s) {
     const uint32_t nb = div_up(B, kGridBlock);
     const uint32_t LP = (L + 7) / 8;
     const uint32_t nblocks = nb * LP * 8;
     if (grad)
-        k_grid_forward<T, D, C, true><<<nblocks, kGridBlock, 0, s>>>(inputs, (const T*)emb, (T*)out, B, L, lv, (T*)dy_dx, gridtype, ac);
+        k_grid_forward<T, D, C, true><<<nblocks, kGridBlock, 0, s>>>(inputs, (const T*)emb, (T*)out, B, L, lv, (T*)dy_dx, gridtype, ac, io);
     else
-        k_grid_forward<T, D, C, false><<<nblocks, kGridBlock, 0, s>>>(inputs, (const T*)emb, (T*)out, B, L, lv, nullptr, gridtype, ac);
+        k_grid_forward<T, D, C, false><<<nblocks, kGridBlock, 0, s>>>(inputs, (const T*)emb, (T*)out, B, L, lv, nullptr, gridtype, ac, io);
 }
 
 template <typename T, int D, int C>
 static void launch_backward(const void* grad, const float* inputs, void* grad_emb, uint32_t B, uint32_t L, const GridLevels& lv, bool gi,
                             const void* dy_dx, void* grad_inputs, uint32_t gridtype, bool ac, void* workspace, size_t workspace_bytes,
-                            hipStream_t s) {
+                            GridIo io, hipStream_t s) {
     const uint32_t nb = div_up(B, kGridBlock);
     if (!grad_emb) {   // frozen table (the rollout's pose gradients): only the input gradient
-        if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
+        if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L, io);
         return;
     }
     // levels accumulated in LDS: worth it from a few thousand points per entry-kilobyte on; the slice must fit kSmallMaxFloats
@@ -970,7 +979,7 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         ensure_dynamic_lds((const void*)kern, (int)(kSmallMaxFloats * sizeof(unsigned long long)));
         const uint32_t n_pb = div_up(B, (uint32_t)kSmallThreads);
         const uint32_t bx = n_pb < 256u ? n_pb : 256u;
-        kern<<<dim3(bx, n_small), kSmallThreads, lds, s>>>((const T*)grad, inputs, (T*)grad_emb, B, lv, gridtype, ac, small_mask);
+        kern<<<dim3(bx, n_small), kSmallThreads, lds, s>>>((const T*)grad, inputs, (T*)grad_emb, B, lv, gridtype, ac, small_mask, io);
     }
     // hashed levels of an fp16, two-feature table: binned two-pass scatter instead of one scattered atomic per update
     uint32_t done_mask = small_mask, n_done = n_small;
@@ -1013,10 +1022,10 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
                 (void)hipMemsetAsync(plan.fill, 0, (size_t)n * kBinMax * kBinShards * kFillStride * sizeof(uint32_t), s);
                 if (merge)
                     k_grid_bwd_bin<D, NT, true><<<dim3(n_pb, n), NT, lds_merge, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype,
-                                                                                     ac, bl, first, plan);
+                                                                                     ac, bl, first, plan, io);
                 else
                     k_grid_bwd_bin<D, NT, false><<<dim3(n_pb, n), NT, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype,
-                                                                                    ac, bl, first, plan);
+                                                                                    ac, bl, first, plan, io);
                 // a bin holds at most 32 regions of `cap` records: no more reducing workgroups than that can keep busy
                 uint32_t max_split = 1;
                 while (max_split < kBinSplit && (size_t)level_records / kBinMax >= (size_t)2 * max_split * kBinSplitMin) max_split *= 2;
@@ -1050,9 +1059,9 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         uint32_t n_rest = 0;
         for (uint32_t l = 0; l < L; l++)
             if (!((done_mask >> l) & 1u)) rest.level[n_rest++] = l;
-        k_grid_backward<T, D, C><<<nb * n_rest, kGridBlock, 0, s>>>((const T*)grad, inputs, (T*)grad_emb, B, L, lv, gridtype, ac, rest, n_rest);
+        k_grid_backward<T, D, C><<<nb * n_rest, kGridBlock, 0, s>>>((const T*)grad, inputs, (T*)grad_emb, B, L, lv, gridtype, ac, rest, n_rest, io);
     }
-    if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L);
+    if (gi) k_grid_input_backward<T, D, C><<<div_up(B * D, kGridBlock), kGridBlock, 0, s>>>((const T*)grad, (const T*)dy_dx, (T*)grad_inputs, B, L, io);
 }
 
 #define NGP_DISPATCH_DC(FN, T, ...)                                              \
@@ -1074,11 +1083,12 @@ using namespace ngp;
 
 extern "C" {
 
-int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs, uint32_t B,
-                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
-                            uint32_t gridtype, int align_corners, int dtype, const void* cell_tables, uint32_t cell_levels,
-                            ngp_stream_t stream) {
+static int grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs, uint32_t B,
+                               uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
+                               uint32_t gridtype, int align_corners, int dtype, const void* cell_tables, uint32_t cell_levels,
+                               GridIo io, ngp_stream_t stream) {
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(io.ls % C == 0 && io.bs % C == 0 && io.ls >= C && io.bs >= C, "grid_encode_forward: strides must be non-zero multiples of C");
     NGP_REQUIRE(inputs && embeddings && offsets_host && outputs, "grid_encode_forward: null pointer");
     NGP_REQUIRE(D == 2 || D == 3, "GridEncoding: D must be 2 or 3 on this build (got %u)", D);
     NGP_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, "GridEncoding: C must be 1, 2, 4, or 8.");
@@ -1111,24 +1121,25 @@ int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const i
         // the alternative -- groups of four levels on XCD pairs, one gathered hashed level per group when twelve levels come from
         // records -- is 12-20 % slower in every case (more distinct hashed levels per L2).
         const uint32_t nblocks = 8 * ((L + 15) / 16) * div_up(B, kGridBlock);
-        if (g) k_grid_forward_g4<true, true><<<nblocks, kGridBlock, 0, s>>>(inputs, e16, o16, B, L, lv, d16, gridtype, ac, cells, cells ? cell_levels : 0, cell_off);
-        else k_grid_forward_g4<false, true><<<nblocks, kGridBlock, 0, s>>>(inputs, e16, o16, B, L, lv, nullptr, gridtype, ac, cells, cells ? cell_levels : 0, cell_off);
+        if (g) k_grid_forward_g4<true, true><<<nblocks, kGridBlock, 0, s>>>(inputs, e16, o16, B, L, lv, d16, gridtype, ac, cells, cells ? cell_levels : 0, cell_off, io);
+        else k_grid_forward_g4<false, true><<<nblocks, kGridBlock, 0, s>>>(inputs, e16, o16, B, L, lv, nullptr, gridtype, ac, cells, cells ? cell_levels : 0, cell_off, io);
     } else if (dtype == NGP_F32) {
-        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, s)
+        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, io, s)
     } else {
-        NGP_DISPATCH_DC(launch_forward, _Float16, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, s)
+        NGP_DISPATCH_DC(launch_forward, _Float16, inputs, embeddings, outputs, B, L, lv, g, dy_dx, gridtype, ac, io, s)
     }
     return check_launch("grid_encode_forward");
 }
 
-int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets_host,
-                             void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                             int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int dtype,
-                             void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+static int grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets_host,
+                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int dtype,
+                                void* workspace, size_t workspace_bytes, GridIo io, ngp_stream_t stream) {
     (void)embeddings;
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(grad && inputs && offsets_host, "grid_encode_backward: null pointer");
     NGP_REQUIRE(grad_embeddings || calc_grad_inputs, "grid_encode_backward: neither the table gradient nor the input gradient is requested");
+    NGP_REQUIRE(io.ls % C == 0 && io.bs % C == 0 && io.ls >= C && io.bs >= C, "grid_encode_backward: strides must be non-zero multiples of C");
     NGP_REQUIRE(D == 2 || D == 3, "GridEncoding: D must be 2 or 3 on this build (got %u)", D);
     NGP_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, "GridEncoding: C must be 1, 2, 4, or 8.");
     NGP_REQUIRE(L >= 1 && L <= (uint32_t)kMaxLevels, "GridEncoding: L must be in [1, %d]", kMaxLevels);
@@ -1142,19 +1153,51 @@ int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* 
     const bool gi = calc_grad_inputs != 0, ac = align_corners != 0;
     if (dtype == NGP_F32) {
         NGP_DISPATCH_DC(launch_backward, float, grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace,
-                        workspace_bytes, s)
+                        workspace_bytes, io, s)
     } else {
         switch (D * 16 + C) {
-            case 2 * 16 + 2: launch_backward<_Float16, 2, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
-            case 2 * 16 + 4: launch_backward<_Float16, 2, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
-            case 2 * 16 + 8: launch_backward<_Float16, 2, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
-            case 3 * 16 + 2: launch_backward<_Float16, 3, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
-            case 3 * 16 + 4: launch_backward<_Float16, 3, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
-            case 3 * 16 + 8: launch_backward<_Float16, 3, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, s); break;
+            case 2 * 16 + 2: launch_backward<_Float16, 2, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, io, s); break;
+            case 2 * 16 + 4: launch_backward<_Float16, 2, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, io, s); break;
+            case 2 * 16 + 8: launch_backward<_Float16, 2, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, io, s); break;
+            case 3 * 16 + 2: launch_backward<_Float16, 3, 2>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, io, s); break;
+            case 3 * 16 + 4: launch_backward<_Float16, 3, 4>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, io, s); break;
+            case 3 * 16 + 8: launch_backward<_Float16, 3, 8>(grad, inputs, grad_embeddings, B, L, lv, gi, dy_dx, grad_inputs, gridtype, ac, workspace, workspace_bytes, io, s); break;
             default: break;
         }
     }
     return check_launch("grid_encode_backward");
+}
+
+int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs, uint32_t B,
+                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
+                            uint32_t gridtype, int align_corners, int dtype, const void* cell_tables, uint32_t cell_levels,
+                            ngp_stream_t stream) {
+    return grid_encode_forward(inputs, embeddings, offsets_host, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype, align_corners, dtype,
+                               cell_tables, cell_levels, GridIo{B * C, C}, stream);
+}
+
+int ngp_grid_encode_forward_strided(const float* inputs, const void* embeddings, const int32_t* offsets_host, void* outputs, uint32_t B,
+                                    uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, void* dy_dx,
+                                    uint32_t gridtype, int align_corners, int dtype, const void* cell_tables, uint32_t cell_levels,
+                                    uint32_t level_stride, uint32_t point_stride, ngp_stream_t stream) {
+    return grid_encode_forward(inputs, embeddings, offsets_host, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype, align_corners, dtype,
+                               cell_tables, cell_levels, GridIo{level_stride, point_stride}, stream);
+}
+
+int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets_host,
+                             void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int dtype,
+                             void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
+    return grid_encode_backward(grad, inputs, embeddings, offsets_host, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_inputs,
+                                gridtype, align_corners, dtype, workspace, workspace_bytes, GridIo{B * C, C}, stream);
+}
+
+int ngp_grid_encode_backward_strided(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets_host,
+                                     void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                     int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, int dtype,
+                                     void* workspace, size_t workspace_bytes, uint32_t level_stride, uint32_t point_stride, ngp_stream_t stream) {
+    return grid_encode_backward(grad, inputs, embeddings, offsets_host, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx, grad_inputs,
+                                gridtype, align_corners, dtype, workspace, workspace_bytes, GridIo{level_stride, point_stride}, stream);
 }
 
 size_t ngp_grid_encode_backward_workspace(uint32_t B, uint32_t D, uint32_t C, uint32_t L, int dtype) {

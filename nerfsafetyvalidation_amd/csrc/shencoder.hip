@@ -143,6 +143,129 @@ static void launch_sh(const float* in, float* out, uint32_t B, uint32_t D, bool 
     else k_sh_forward<DEG, false><<<div_up(B, kShBlock), kShBlock, 0, s>>>(in, out, B, D, k, nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The elementwise steps between the two FFMLPs of nerf/network_ff.py (:55-70 forward, autograd backward), one kernel each way instead
+// of torch's slice / cast / exp / cat / zeros / add chain (a dozen launches, ~15 ms of a 640 k-ray training step: DESIGN.md section 4).
+// Same values as that chain:
+//   sigma        = exp(float(h[:, 0]))                                       (activation.py:8-12 under autocast: fp32 exp of the half)
+//   colour input = [ half(SH_4(dir)) | h[:, 1:16] | 0 ]                      (network_ff.py:66-69; the FFMLP's cast rounds the fp32 SH values)
+//   d h[:, 0]    = half(d sigma * exp(clamp(float(h[:, 0]), -15, 15)))      (activation.py:14-17)
+//   d h[:, 1:16] = d colour input[:, 16:31]
+//   rgb          = half(1 / (1 + exp(-float(o[:, :3]))))                      (torch.sigmoid on the half output: fp32 op-math, one rounding)
+//   d o[:, :3]   = half(half(d rgb * half(1 - rgb)) * rgb)  (torch's sigmoid_backward on halves: c10::Half steps),  d o[:, 3:16] = 0
+// Rows B <= b < B_pad (the FFMLP's row padding, ffmlp.py:156-158) are written as zeros.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct alignas(16) Half8 { _Float16 v[8]; };
+
+__global__ void __launch_bounds__(kShBlock) k_ff_sigma_color_input(const _Float16* __restrict__ h, const float* __restrict__ dirs, uint32_t B,
+                                                                   uint32_t B_pad, ShConst k, float* __restrict__ sigma,
+                                                                   _Float16* __restrict__ cin) {
+    const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
+    if (b >= B_pad) return;
+    Half8* out = reinterpret_cast<Half8*>(cin + (size_t)b * 32);
+    Half8 o[4];
+    if (b >= B) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[i].v[j] = (_Float16)0;
+            out[i] = o[i];
+        }
+        return;
+    }
+    const Half8* hr = reinterpret_cast<const Half8*>(h + (size_t)b * 16);
+    const Half8 h0 = hr[0], h1 = hr[1];
+    sigma[b] = expf((float)h0.v[0]);
+    ShBasis<4> s;
+    s.build(dirs[(size_t)b * 3], dirs[(size_t)b * 3 + 1], dirs[(size_t)b * 3 + 2]);
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+        for (int m = -l; m <= l; m++) {
+            float v, gx, gy, gz;
+            sh_term<4, false>(s, k, l, m, v, gx, gy, gz);
+            const int i = l * l + l + m;
+            asm volatile("" : "+v"(v));      // the fp32 value the operator writes, THEN rounded (no product-and-convert folding, see below)
+            o[i >> 3].v[i & 7] = (_Float16)v;
+        }
+#pragma unroll
+    for (int j = 0; j < 7; j++) o[2].v[j] = h0.v[j + 1];
+    o[2].v[7] = h1.v[0];
+#pragma unroll
+    for (int j = 0; j < 7; j++) o[3].v[j] = h1.v[j + 1];
+    o[3].v[7] = (_Float16)0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = o[i];
+}
+
+__global__ void __launch_bounds__(kShBlock) k_ff_sigma_color_input_bwd(const _Float16* __restrict__ h, const float* __restrict__ g_sigma,
+                                                                       const _Float16* __restrict__ g_cin, uint32_t B, uint32_t B_pad,
+                                                                       _Float16* __restrict__ g_h) {
+    const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
+    if (b >= B_pad) return;
+    Half8 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[i].v[j] = (_Float16)0;
+    if (b < B) {
+        if (g_sigma) {
+            const float x = (float)h[(size_t)b * 16];
+            // torch multiplies in fp32 and the cast's backward then rounds to half: two roundings.  The compiler would fold the product
+            // and the conversion into one v_fma_mixlo_f16 (ONE rounding: differs on ties); the empty asm keeps the fp32 product
+            float p = g_sigma[b] * expf(fminf(fmaxf(x, -15.0f), 15.0f));
+            asm volatile("" : "+v"(p));
+            o[0].v[0] = (_Float16)p;
+        }
+        if (g_cin) {
+            const Half8* gr = reinterpret_cast<const Half8*>(g_cin + (size_t)b * 32);
+            const Half8 g2 = gr[2], g3 = gr[3];
+#pragma unroll
+            for (int j = 0; j < 7; j++) o[0].v[j + 1] = g2.v[j];
+            o[1].v[0] = g2.v[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) o[1].v[j + 1] = g3.v[j];
+        }
+    }
+    Half8* out = reinterpret_cast<Half8*>(g_h + (size_t)b * 16);
+    out[0] = o[0];
+    out[1] = o[1];
+}
+
+__global__ void __launch_bounds__(kShBlock) k_ff_rgb(const _Float16* __restrict__ o16, uint32_t B, _Float16* __restrict__ rgb) {
+    const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint2 raw = *reinterpret_cast<const uint2*>(o16 + (size_t)b * 16);
+    struct alignas(8) H4 { _Float16 v[4]; };
+    const H4 v = __builtin_bit_cast(H4, raw);
+#pragma unroll
+    for (int c = 0; c < 3; c++) rgb[(size_t)b * 3 + c] = (_Float16)(1.0f / (1.0f + expf(-(float)v.v[c])));
+}
+
+__global__ void __launch_bounds__(kShBlock) k_ff_rgb_bwd(const _Float16* __restrict__ g_rgb, const _Float16* __restrict__ rgb, uint32_t B,
+                                                         uint32_t B_pad, _Float16* __restrict__ g_o16) {
+    const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
+    if (b >= B_pad) return;
+    Half8 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[i].v[j] = (_Float16)0;
+    if (b < B) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            // torch's sigmoid_backward on halves: `a * (scalar_t(1) - b) * b` in c10::Half arithmetic, every step rounded to half
+            const _Float16 g = g_rgb[(size_t)b * 3 + c], y = rgb[(size_t)b * 3 + c];
+            const _Float16 t1 = (_Float16)(1.0f - (float)y);
+            const _Float16 t2 = (_Float16)((float)g * (float)t1);
+            o[0].v[c] = (_Float16)((float)t2 * (float)y);
+        }
+    }
+    Half8* out = reinterpret_cast<Half8*>(g_o16 + (size_t)b * 16);
+    out[0] = o[0];
+    out[1] = o[1];
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -182,6 +305,52 @@ int ngp_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, u
     ProfScope prof("sh_encode_backward", (hipStream_t)stream, B);
     k_sh_backward<<<div_up(B * D, kShBlock), kShBlock, 0, (hipStream_t)stream>>>(grad, B, D, C * C, dy_dx, grad_inputs);
     return check_launch("sh_encode_backward");
+}
+
+int ngp_ff_sigma_color_input(const uint16_t* h, const float* dirs, uint32_t B, uint32_t B_pad, float* sigma, uint16_t* color_input,
+                             ngp_stream_t stream) {
+    if (B_pad == 0) return NGP_OK;
+    NGP_REQUIRE(B <= B_pad, "ff_sigma_color_input: B (%u) exceeds B_pad (%u)", B, B_pad);
+    NGP_REQUIRE(color_input && (B == 0 || (h && dirs && sigma)), "ff_sigma_color_input: null pointer");
+    NGP_REQUIRE((((uintptr_t)h | (uintptr_t)color_input) & 15) == 0, "ff_sigma_color_input: rows must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("ff_sigma_color_input", s, B);
+    k_ff_sigma_color_input<<<div_up(B_pad, kShBlock), kShBlock, 0, s>>>((const _Float16*)h, dirs, B, B_pad, sh_constants(), sigma, (_Float16*)color_input);
+    return check_launch("ff_sigma_color_input");
+}
+
+int ngp_ff_sigma_color_input_backward(const uint16_t* h, const float* grad_sigma, const uint16_t* grad_color_input, uint32_t B, uint32_t B_pad,
+                                      uint16_t* grad_h, ngp_stream_t stream) {
+    if (B_pad == 0) return NGP_OK;
+    NGP_REQUIRE(B <= B_pad, "ff_sigma_color_input_backward: B (%u) exceeds B_pad (%u)", B, B_pad);
+    NGP_REQUIRE(grad_h && (B == 0 || h), "ff_sigma_color_input_backward: null pointer");
+    NGP_REQUIRE((((uintptr_t)grad_h | (uintptr_t)grad_color_input) & 15) == 0, "ff_sigma_color_input_backward: rows must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("ff_sigma_color_input_backward", s, B);
+    k_ff_sigma_color_input_bwd<<<div_up(B_pad, kShBlock), kShBlock, 0, s>>>((const _Float16*)h, grad_sigma, (const _Float16*)grad_color_input, B, B_pad,
+                                                                           (_Float16*)grad_h);
+    return check_launch("ff_sigma_color_input_backward");
+}
+
+int ngp_ff_rgb(const uint16_t* outputs16, uint32_t B, uint16_t* rgb, ngp_stream_t stream) {
+    if (B == 0) return NGP_OK;
+    NGP_REQUIRE(outputs16 && rgb, "ff_rgb: null pointer");
+    NGP_REQUIRE(((uintptr_t)outputs16 & 7) == 0, "ff_rgb: rows must be 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("ff_rgb", s, B);
+    k_ff_rgb<<<div_up(B, kShBlock), kShBlock, 0, s>>>((const _Float16*)outputs16, B, (_Float16*)rgb);
+    return check_launch("ff_rgb");
+}
+
+int ngp_ff_rgb_backward(const uint16_t* grad_rgb, const uint16_t* rgb, uint32_t B, uint32_t B_pad, uint16_t* grad_outputs16, ngp_stream_t stream) {
+    if (B_pad == 0) return NGP_OK;
+    NGP_REQUIRE(B <= B_pad, "ff_rgb_backward: B (%u) exceeds B_pad (%u)", B, B_pad);
+    NGP_REQUIRE(grad_outputs16 && (B == 0 || (grad_rgb && rgb)), "ff_rgb_backward: null pointer");
+    NGP_REQUIRE(((uintptr_t)grad_outputs16 & 15) == 0, "ff_rgb_backward: rows must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("ff_rgb_backward", s, B);
+    k_ff_rgb_bwd<<<div_up(B_pad, kShBlock), kShBlock, 0, s>>>((const _Float16*)grad_rgb, (const _Float16*)rgb, B, B_pad, (_Float16*)grad_outputs16);
+    return check_launch("ff_rgb_backward");
 }
 
 }  // extern "C"

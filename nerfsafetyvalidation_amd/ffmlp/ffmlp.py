@@ -17,8 +17,10 @@ class _ffmlp_forward(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                inference=False, calc_grad_inputs=False):
-        B = inputs.shape[0]
+                inference=False, calc_grad_inputs=False, planes=False):
+        # planes (this build): inputs are the hash-grid operator's level planes [input_dim/2, B, 2] (ngp_ffmlp_forward_planes), read --
+        # and their gradient written -- in place
+        B = inputs.shape[1] if planes else inputs.shape[0]
         inputs = inputs.contiguous()
         weights = weights.contiguous()
         if inputs.dtype != torch.half or weights.dtype != torch.half:
@@ -26,7 +28,16 @@ class _ffmlp_forward(Function):
             raise RuntimeError("FFMLP: inputs and weights must be half tensors (call under autocast or cast explicitly)")
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         lib = _lib.lib()
-        if not inference:
+        ctx.planes = planes
+        if planes:
+            forward_buffer = None if inference else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            _lib.check(lib.ngp_ffmlp_forward_planes(_lib.ptr(inputs), _lib.ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
+                                                    activation, output_activation, _lib.ptr(forward_buffer), _lib.ptr(outputs),
+                                                    _lib.stream()), "ffmlp_forward_planes")
+            if not inference:
+                ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
+                ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
+        elif not inference:
             forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             _lib.check(lib.ngp_ffmlp_forward(_lib.ptr(inputs), _lib.ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
                                              activation, output_activation, _lib.ptr(forward_buffer), _lib.ptr(outputs),
@@ -56,13 +67,14 @@ class _ffmlp_forward(Function):
         # backward passes running concurrently on other streams never share it
         wbytes = lib.ngp_ffmlp_backward_workspace(B, input_dim, hidden_dim, num_layers)
         work = torch.empty((wbytes + 3) // 4, dtype=torch.float32, device=grad.device)
-        _lib.check(lib.ngp_ffmlp_backward(_lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(weights), _lib.ptr(forward_buffer), B,
-                                          input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                                          int(calc_grad_inputs), _lib.ptr(backward_buffer), _lib.ptr(grad_inputs),
-                                          _lib.ptr(grad_weights), _lib.ptr(work), wbytes, _lib.stream()), "ffmlp_backward")
+        fn = lib.ngp_ffmlp_backward_planes if ctx.planes else lib.ngp_ffmlp_backward
+        _lib.check(fn(_lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(weights), _lib.ptr(forward_buffer), B,
+                      input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                      int(calc_grad_inputs), _lib.ptr(backward_buffer), _lib.ptr(grad_inputs),
+                      _lib.ptr(grad_weights), _lib.ptr(work), wbytes, _lib.stream()), "ffmlp_backward")
         if calc_grad_inputs:
-            return grad_inputs, grad_weights, None, None, None, None, None, None, None, None
-        return None, grad_weights, None, None, None, None, None, None, None, None
+            return grad_inputs, grad_weights, None, None, None, None, None, None, None, None, None
+        return None, grad_weights, None, None, None, None, None, None, None, None, None
 
 
 ffmlp_forward = _ffmlp_forward.apply
@@ -121,3 +133,13 @@ class FFMLP(nn.Module):
         if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
             outputs = outputs[:B, :self.output_dim]
         return outputs
+
+    def forward_padded(self, inputs, planes=False):
+        """(this build) inputs [B, input_dim] with B % 16 == 0 -> the kernel's own [B, padded_output_dim] output, unsliced: for callers
+        that padded the rows themselves and read the output columns in their next kernel (nerf/network_ff.py).
+        planes: inputs are level planes [input_dim/2, B, 2] as the hash-grid operator writes them (64-wide networks)."""
+        B = inputs.shape[1] if planes else inputs.shape[0]
+        if B % 16 != 0 or (planes and (inputs.dim() != 3 or inputs.shape[0] * 2 != self.input_dim or inputs.shape[2] != 2 or self.hidden_dim != 64)):
+            raise ValueError("FFMLP.forward_padded: rows must be a multiple of 16 (planes: [input_dim/2, B, 2] into a 64-wide network)")
+        return ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+                             self.activation, self.output_activation, not self.training, inputs.requires_grad, planes)

@@ -115,6 +115,27 @@ def invalidate_derived(param):
     _forget(id(param))
 
 
+def _table_for_call(embeddings, offsets, B, D, C, L, S, H, gridtype, align_corners):
+    """the table a forward call reads (and, for tables that are being evaluated rather than trained, its per-cell records)"""
+    # manual autocast: half embeddings only when C is even (grid.py:36-39).  The fp16 copy is kept per version of the parameter
+    # (the reference converts the whole table on every call); a table that is evaluated repeatedly without changing also gets
+    # its per-cell corner records, which the kernel reads instead of gathering (same values: bit-identical outputs).
+    cells, cell_levels = None, 0
+    if torch.is_autocast_enabled("cuda") and C % 2 == 0:
+        if embeddings.dtype == torch.float32 and isinstance(embeddings, nn.Parameter):
+            ent = derived_tables(embeddings)
+            embeddings = ent.table_for_current_stream()
+            # the records take ~9 ms to build and save ~30 % of a forward: worth it once this version of the table has encoded
+            # tens of millions of points (a frame rendered operator by operator), not for the few chunks of a density-grid
+            # update between two optimiser steps
+            ent.points += B
+            if ent.points >= _CELLS_AFTER_POINTS and ((ent.seen >= 2 and not torch.is_grad_enabled()) or ent.seen >= 8) and D == 3 and C == 2 and L == 16:
+                cells, cell_levels = ent.ensure_cells(_lib.host_i32(offsets), S, H, gridtype, align_corners)
+        else:
+            embeddings = embeddings.to(torch.half)
+    return embeddings, cells, cell_levels
+
+
 class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
@@ -130,22 +151,7 @@ class _grid_encode(Function):
         S = float(np.log2(per_level_scale))  # crosses the ABI as a C float, as in the reference (grid.py:33)
         H = base_resolution
 
-        # manual autocast: half embeddings only when C is even (grid.py:36-39).  The fp16 copy is kept per version of the parameter
-        # (the reference converts the whole table on every call); a table that is evaluated repeatedly without changing also gets
-        # its per-cell corner records, which the kernel reads instead of gathering (same values: bit-identical outputs).
-        cells, cell_levels = None, 0
-        if torch.is_autocast_enabled("cuda") and C % 2 == 0:
-            if embeddings.dtype == torch.float32 and isinstance(embeddings, nn.Parameter):
-                ent = derived_tables(embeddings)
-                embeddings = ent.table_for_current_stream()
-                # the records take ~9 ms to build and save ~30 % of a forward: worth it once this version of the table has encoded
-                # tens of millions of points (a frame rendered operator by operator), not for the few chunks of a density-grid
-                # update between two optimiser steps
-                ent.points += B
-                if ent.points >= _CELLS_AFTER_POINTS and ((ent.seen >= 2 and not torch.is_grad_enabled()) or ent.seen >= 8) and D == 3 and C == 2 and L == 16:
-                    cells, cell_levels = ent.ensure_cells(_lib.host_i32(offsets), S, H, gridtype, align_corners)
-            else:
-                embeddings = embeddings.to(torch.half)
+        embeddings, cells, cell_levels = _table_for_call(embeddings, offsets, B, D, C, L, S, H, gridtype, align_corners)
         embeddings = embeddings.contiguous()
 
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
@@ -157,7 +163,9 @@ class _grid_encode(Function):
                                                int(align_corners), _lib.dtype_code(embeddings), _lib.ptr(cells), cell_levels, _lib.stream()),
                    "grid_encode_forward")
 
-        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)  # [L,B,C] -> [B, L*C] (grid.py:52)
+        # [L,B,C] -> [B, L*C] (grid.py:52).  (The scattered 4-byte writes of producing [B, L*C] in the kernel cost more than this copy:
+        # 8.9 vs 5.3 + 1.8 ms on 29.5 M points.  Where the consumer is an FFMLP, _grid_encode_planes hands it the planes as they are.)
+        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
 
         if dy_dx is None:
             dy_dx = torch.empty(1, device=inputs.device, dtype=embeddings.dtype)  # placeholder, as the reference saves
@@ -196,6 +204,59 @@ class _grid_encode(Function):
 
 
 grid_encode = _grid_encode.apply
+
+
+class _grid_encode_planes(Function):
+    """(this build) the operator's own level planes, for a consumer that reads them in place (ffmlp.FFMLP.forward_padded(planes=True)):
+    inputs [B,D] -> [L, Bp, C] with Bp = B rounded up to `rows_multiple`, rows B..Bp-1 zero (the FFMLP's row padding, ffmlp.py:156-158,
+    without its copy of the batch).  Backward takes the gradient in the same layout.  No gradient to the inputs."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, rows_multiple):
+        inputs = inputs.contiguous()
+        if inputs.dtype != torch.float32:
+            inputs = inputs.float()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = base_resolution
+        Bp = B + (-B) % rows_multiple
+        embeddings, cells, cell_levels = _table_for_call(embeddings, offsets, B, D, C, L, S, H, gridtype, align_corners)
+        embeddings = embeddings.contiguous()
+        outputs = torch.empty(L, Bp, C, device=inputs.device, dtype=embeddings.dtype)
+        if Bp != B:
+            outputs[:, B:].zero_()
+        _lib.check(_lib.lib().ngp_grid_encode_forward_strided(_lib.ptr(inputs), _lib.ptr(embeddings), _lib.host_i32(offsets), _lib.ptr(outputs),
+                                                              B, D, C, L, S, H, 0, None, gridtype, int(align_corners),
+                                                              _lib.dtype_code(embeddings), _lib.ptr(cells), cell_levels, Bp * C, C, _lib.stream()),
+                   "grid_encode_forward")
+        ctx.save_for_backward(inputs, embeddings, offsets)
+        ctx.dims = [B, D, C, L, S, H, gridtype, Bp]
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        inputs, embeddings, offsets = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, Bp = ctx.dims
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None, None, None
+        grad = grad.contiguous().to(embeddings.dtype)          # [L, Bp, C], read in place
+        grad_embeddings = torch.zeros_like(embeddings)
+        lib = _lib.lib()
+        wbytes = lib.ngp_grid_encode_backward_workspace(B, D, C, L, _lib.dtype_code(embeddings))
+        work = torch.empty(wbytes, dtype=torch.uint8, device=grad.device) if wbytes else None
+        _lib.check(lib.ngp_grid_encode_backward_strided(_lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(embeddings), _lib.host_i32(offsets),
+                                                        _lib.ptr(grad_embeddings), B, D, C, L, S, H, 0, None, None, gridtype,
+                                                        int(ctx.align_corners), _lib.dtype_code(embeddings), _lib.ptr(work), wbytes, Bp * C, C,
+                                                        _lib.stream()), "grid_encode_backward")
+        return None, grad_embeddings, None, None, None, None, None, None
+
+
+grid_encode_planes = _grid_encode_planes.apply
 
 
 class GridEncoder(nn.Module):
@@ -242,6 +303,13 @@ class GridEncoder(nn.Module):
                 f"{int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
                 f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} "
                 f"gridtype={self.gridtype} align_corners={self.align_corners}")
+
+    def forward_planes(self, inputs, bound=1, rows_multiple=16):
+        """(this build) inputs [B, input_dim] in [-bound, bound], no gradient to them -> the level planes [num_levels, Bp, level_dim]
+        with the row count padded to a multiple of `rows_multiple` (zero rows): see _grid_encode_planes"""
+        inputs = (inputs + bound) / (2 * bound)
+        return grid_encode_planes(inputs.view(-1, self.input_dim), self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                                  self.gridtype_id, self.align_corners, rows_multiple)
 
     def forward(self, inputs, bound=1):
         """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels*level_dim]"""

@@ -207,7 +207,8 @@ class NeRFRenderer(nn.Module):
                                                                 self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                 force_all_rays, dt_gamma, max_steps)
         sigmas, rgbs = self(xyzs, dirs)
-        sigmas = self.density_scale * sigmas
+        if self.density_scale != 1:      # (x * 1 is x: the launch and its backward are skipped, the values are the reference's)
+            sigmas = self.density_scale * sigmas
         if sigmas.dim() != 1:
             raise RuntimeError("run_cuda: the network must return one density per sample (residual stacks are not part of this path)")
         return (*raymarching.composite_rays_train(sigmas, rgbs, deltas, rays), sigmas, rgbs)

@@ -55,9 +55,12 @@ REPS = 3
 LOSS_SCALE = 65536.0
 grad_nonzero = None
 M = None
+PROF = os.environ.get("NGP_BENCH_NO_PROF") is None   # (the per-operator events serialise nothing, but cost a few host calls per launch)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 for it in range(1 + REPS):
     if it == 1:
-        torch.cuda.synchronize(); lib.ngp_prof_reset(); lib.ngp_prof_enable(1)
+        torch.cuda.synchronize(); lib.ngp_prof_reset(); lib.ngp_prof_enable(1 if PROF else 0)
+        ev[0].record()
     rays = get_rays(poses[it:it + 1], sc.intrinsics, H, W)
     with torch.autocast("cuda", dtype=torch.float16):
         out = model.render(rays["rays_o"], rays["rays_d"], staged=False, bg_color=1, perturb=True, force_all_rays=False)
@@ -74,10 +77,14 @@ for it in range(1 + REPS):
             p_.grad.div_(LOSS_SCALE)
     opt.step()
     M = int(model.step_counter[(model.local_step - 1) % 16][0].item())
+ev[1].record()
 torch.cuda.synchronize(); lib.ngp_prof_enable(0)
+step_ms = ev[0].elapsed_time(ev[1]) / REPS
 n_param = sum(p.numel() for p in model.parameters())
 Mp = M + 128 - M % 128
-print(json.dumps({"frame": f"{H}x{W}", "rays": N, "samples_of_the_step": M, "parameters": n_param}))
+print(json.dumps({"frame": f"{H}x{W}", "rays": N, "samples_of_the_step": M, "parameters": n_param,
+                  "training_step_ms": round(step_ms, 2), "training_step_what": f"get_rays -> render (march_rays_train, encoders, FFMLPs, composite) -> loss -> "
+                  f"backward -> unscale -> Adam, all {N} rays in one batch, wall clock between two events on the stream over {REPS} steps"}))
 line("get_rays", "get_rays", N, "rays", 24 * N + 64)
 line("near_far_from_aabb", "near_far_from_aabb", N, "rays", 32 * N)
 line("march_rays_train (two passes + ray-order offsets)", "march_rays_train", M, "samples", 32 * M + (24 + 8 + 12) * N)

@@ -266,6 +266,103 @@ def test_grid_encode_forward_bit_exact(device, dtype, D, C):
                                    **(dict(rtol=1e-4, atol=1e-5) if dtype == np.float32 else dict(rtol=5e-2, atol=5e-2)))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("D,C,B", [(3, 2, 3001), (3, 4, 777), (2, 2, 1500), (3, 2, 200_000)])
+def test_grid_encode_strided_layouts_agree_with_the_level_major_operator(device, dtype, D, C, B):
+    """ngp_grid_encode_forward / _backward keep the reference operator's [L,B,C] arrays (gridencoder.cu:448-478); the _strided entries
+    take the position of a (level, point) group from the caller: level planes with a padded row count (what the FFMLP reads in place)
+    and the module's [B, L*C] (grid.py:52,72).  Same kernels, same arithmetic: outputs bit-identical, untouched padding untouched,
+    gradients identical where the kernels use no atomics (input gradient) and within the atomics' ordering noise for the table."""
+    from nerfsafetyvalidation_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(11)
+    L, log2T = (16, 19) if D == 3 else (8, 15)
+    offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=log2T, desired_resolution=2048)
+    S = float(np.log2(pls))
+    td = torch.float32 if dtype == np.float32 else torch.float16
+    code = _lib.NGP_F32 if dtype == np.float32 else _lib.NGP_F16
+    emb = torch.from_numpy(rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32)).to(device).to(td)
+    # ray-ordered points (the training batch's shape) with an out-of-range one
+    x = np.clip(rng.uniform(0, 1, (B // 50 + 1, 1, D)) + np.linspace(0, 0.3, 50)[None, :, None] * rng.normal(size=(B // 50 + 1, 1, D)), 0, 1)
+    x = x.reshape(-1, D)[:B].astype(np.float32)
+    x[5, 0] = 1.5
+    x_t = torch.from_numpy(x).to(device)
+    host = _lib.host_i32(torch.from_numpy(np.asarray(offsets, np.int32)))
+    Bp = B + (-B) % 16 + 16
+    st = _lib.stream()
+    out_l = torch.empty(L, B, C, dtype=td, device=device)
+    dy_l = torch.empty(B, L * D * C, dtype=td, device=device)
+    _lib.check(lib.ngp_grid_encode_forward(_lib.ptr(x_t), _lib.ptr(emb), host, _lib.ptr(out_l), B, D, C, L, S, 16, 1, _lib.ptr(dy_l), 0, 0, code, None, 0, st), "fwd")
+    assert float(out_l.float().abs().max()) > 0.1 and not bool(out_l[:, 5].any())
+    g_rows = torch.from_numpy(rng.normal(size=(B, L * C)).astype(np.float32)).to(device).to(td)
+    g_l = g_rows.view(B, L, C).permute(1, 0, 2).contiguous()
+
+    def backward(fn, g, *strides):
+        ge = torch.zeros_like(emb)
+        gi = torch.zeros(B, D, dtype=td, device=device)
+        wb = lib.ngp_grid_encode_backward_workspace(B, D, C, L, code)
+        work = torch.empty(max(wb, 1), dtype=torch.uint8, device=device)
+        _lib.check(fn(_lib.ptr(g), _lib.ptr(x_t), _lib.ptr(emb), host, _lib.ptr(ge), B, D, C, L, S, 16, 1, _lib.ptr(dy_l), _lib.ptr(gi), 0, 0, code,
+                      _lib.ptr(work) if wb else None, wb, *strides, st), "bwd")
+        return ge.float(), gi
+
+    ge_l, gi_l = backward(lib.ngp_grid_encode_backward, g_l)
+    scale = float(ge_l.abs().max())
+    assert scale > 1
+    tol = 1e-5 if dtype == np.float32 else 4e-3                         # (fp16 atomics round per update: the order shows)
+    for name, shape, strides, view in (("planes", (L, Bp, C), (Bp * C, C), lambda t: t[:, :B]),
+                                       ("rows", (B, L * C), (C, L * C), lambda t: t.view(B, L, C).permute(1, 0, 2))):
+        out = torch.full(shape, 7.0, dtype=td, device=device)
+        dy = torch.empty_like(dy_l)
+        _lib.check(lib.ngp_grid_encode_forward_strided(_lib.ptr(x_t), _lib.ptr(emb), host, _lib.ptr(out), B, D, C, L, S, 16, 1, _lib.ptr(dy), 0, 0, code,
+                                                       None, 0, *strides, st), name)
+        assert torch.equal(view(out), out_l), name
+        assert torch.equal(dy, dy_l), name
+        if name == "planes":
+            assert bool((out[:, B:] == 7.0).all())                   # rows the call does not address stay as they were
+        g = torch.full(shape, float("nan"), dtype=td, device=device)  # (a NaN read from the padding would poison the table gradient)
+        view(g).copy_(g_l)
+        ge, gi = backward(lib.ngp_grid_encode_backward_strided, g, *strides)
+        assert torch.equal(gi, gi_l), name                            # input gradient: no atomics
+        assert float((ge - ge_l).abs().max()) <= tol * scale, name
+    # strides that would tear a feature group apart are refused
+    assert lib.ngp_grid_encode_forward_strided(_lib.ptr(x_t), _lib.ptr(emb), host, _lib.ptr(out_l), B, D, C, L, S, 16, 0, None, 0, 0, code, None, 0,
+                                               B * C + 1 if C > 1 else 0, C, st) != 0
+
+
+@pytest.mark.parametrize("layers,B", [(2, 4096), (3, 1040), (4, 16)])
+def test_ffmlp_level_plane_inputs_equal_row_inputs(device, layers, B):
+    """ngp_ffmlp_forward_planes / _backward_planes: the 64-wide FFMLP reading its 32 inputs from the hash-grid operator's level planes
+    [16, B, 2] and writing their gradient there -- outputs, kept activations, input gradient and weight gradient bit-identical to the
+    row-major call on the permuted copy (ffmlp.cu:636-709)."""
+    from nerfsafetyvalidation_amd.ffmlp import FFMLP
+    from nerfsafetyvalidation_amd.ffmlp.ffmlp import ffmlp_forward
+    torch.manual_seed(layers)
+    net = FFMLP(32, 16, 64, layers).to(device).train()
+    planes = (torch.randn(16, B, 2, device=device) * 0.5).half()
+    rows = planes.permute(1, 0, 2).reshape(B, 32).contiguous()
+    g = torch.randn(B, 16, device=device).half()
+    res = []
+    for x, flag in ((rows, False), (planes, True)):
+        x = x.clone().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = ffmlp_forward(x, net.weights, 32, 16, 64, layers, net.activation, net.output_activation, False, True, flag)
+        y.backward(g)
+        gx = x.grad if not flag else x.grad.permute(1, 0, 2).reshape(B, 32)
+        res.append((y.detach(), gx, net.weights.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].float().abs().max()) > 0 and float(res[0][1].float().abs().max()) > 0 and float(res[0][2].float().abs().max()) > 0
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):     # inference (no kept activations)
+        net.eval()
+        assert torch.equal(net.forward_padded(planes, planes=True), net.forward_padded(rows))
+    # shapes the planes layout is not built for are refused, not mis-read
+    wide = FFMLP(32, 16, 128, 2).to(device)
+    with pytest.raises(ValueError):
+        wide.forward_padded(planes, planes=True)
+
+
 @pytest.mark.parametrize("dtype,n_rays,T,fill_pct", [(np.float32, 600, 100, None), (np.float16, 600, 100, None), (np.float16, 600, 260, None),
                                                      (np.float16, 160000, 1, None), (np.float16, 600, 260, 60), (np.float16, 160000, 1, 20)])
 def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_pct, monkeypatch):

@@ -42,3 +42,56 @@ def test_ffmlp_zero_row_batch_gives_zero_weight_gradients(device):
     torch.cuda.synchronize()
     assert net.weights.grad is not None and int(torch.count_nonzero(net.weights.grad)) == 0
     assert x.grad is not None and x.grad.shape == (0, 32)
+
+
+@pytest.mark.parametrize("B", [4096, 5003, 1])
+def test_network_ff_forward_fused_elementwise_steps_equal_the_torch_chain(device, B):
+    """nerf/network_ff.NeRFNetwork.forward under autocast: the encoder writing [B, 32] with the FFMLP's row padding in place and the
+    one-kernel elementwise steps (ngp_ff_sigma_color_input, ngp_ff_rgb) against the reference's torch chain (network_ff.py:55-70:
+    slice, trunc_exp, SH, cat, zeros, sigmoid) over the same operators -- sigma and rgb bit for bit, the MLP weight gradients bit for
+    bit (fixed-order reductions), the table gradient within the ordering noise of its fp16 atomics."""
+    from nerfsafetyvalidation_amd.nerf.network_ff import NeRFNetwork
+    torch.manual_seed(3)
+    net = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True).to(device).train()
+    with torch.no_grad():
+        net.encoder.embeddings.uniform_(-0.5, 0.5)
+    x = (torch.rand(B, 3, device=device) * 2 - 1) * 2
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=device), dim=-1)
+    gs, gc = torch.randn(B, device=device), torch.randn(B, 3, device=device)
+    out = {}
+    for fused in (True, False):
+        net.fused_heads = fused
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb = net(x, d)
+        assert sigma.dtype == torch.float32 and rgb.dtype == torch.float16 and sigma.shape == (B,) and rgb.shape == (B, 3)
+        ((sigma * gs).sum() * 64 + (rgb.float() * gc).sum() * 64).backward()
+        out[fused] = (sigma.detach(), rgb.detach(), net.sigma_net.weights.grad.clone(), net.color_net.weights.grad.clone(),
+                      net.encoder.embeddings.grad.clone())
+    a, b = out[True], out[False]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):       # the colour net's input itself (SH values rounded once from fp32)
+        from nerfsafetyvalidation_amd.nerf.network_ff import _sigma_color_input
+        h = net.sigma_net(net.encoder(x, bound=net.bound))
+        pad = (-B) % 16
+        hp = torch.cat([h, torch.zeros(pad, 16, dtype=h.dtype, device=device)]) if pad else h
+        _, cin = _sigma_color_input.apply(hp.contiguous(), d.contiguous(), B)
+        assert torch.equal(cin[:B], net._color_input(d, h[..., 1:])) and not bool(cin[B:].any())
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert float(a[0].max()) > 0 and float(a[1].float().std()) > 0
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert float(a[2].abs().max()) > 0 and float(a[3].abs().max()) > 0
+    scale = float(b[4].abs().max())
+    assert scale > 0 and float((a[4] - b[4]).abs().max()) <= 4e-3 * scale
+    # sigma alone (what a density-only loss differentiates): the colour input's gradient is absent, not zero-filled by hand
+    net.fused_heads = True
+    net.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        sigma, _ = net(x, d)
+    (sigma * gs).sum().backward()
+    g_fused = net.sigma_net.weights.grad.clone()
+    net.fused_heads = False
+    net.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        sigma, _ = net(x, d)
+    (sigma * gs).sum().backward()
+    assert torch.equal(g_fused, net.sigma_net.weights.grad)
