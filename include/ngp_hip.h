@@ -65,6 +65,10 @@ NGP_API int ngp_device_count(void);
 /* raymarching.cu:150-158 near_far_from_aabb */
 NGP_API int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
                            float* nears, float* fars, ngp_stream_t stream);
+/* (this build) nerf/renderer.py:376-381 in one launch, in place: image [N,3] += (1 - weights_sum) * bg_color (three HOST floats),
+ * depth [N] = clamp(depth - nears, min 0) / (fars - nears).  Same operations and roundings as the torch lines. */
+NGP_API int ngp_finish_rays(float* image, float* depth, const float* weights_sum, const float* nears, const float* fars,
+                    const float* bg_color3_host, uint32_t N, ngp_stream_t stream);
 /* raymarching.cu:203-211 sph_from_ray */
 NGP_API int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
                      ngp_stream_t stream);
@@ -473,7 +477,7 @@ NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
 /* Diagnostics: uint32[N] device buffer receiving, per ray, an FNV-1a hash over the bit patterns of (dt, deltas[1]) of every
  * sample the fused renderer marched, in order (NULL = off).  Lets a test prove the fused path's sample sequence equal to
  * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 0 / bit 1 disable the coarse occupancy filter, bit 2 the
- * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
+ * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bit 14 runs every multi-iteration launch as planned (no cut before the network from the march's own counts), bit 15 keeps the work items of k_render_iter at 64 list entries, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
 /* Diagnostics: the 32 hash-grid features of xyzs [M,3] (positions in [-bound, bound]) exactly as the fused kernels' gather forms them

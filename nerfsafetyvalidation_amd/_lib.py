@@ -44,6 +44,7 @@ SIGNATURES = {
     "ngp_last_error": [],
     "ngp_version": [],
     "ngp_device_count": [],
+    "ngp_finish_rays": [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), _u32, _vp],
     "ngp_near_far_from_aabb": [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
     "ngp_sph_from_ray": [_vp, _vp, _f32, _u32, _vp, _vp],
     "ngp_morton3D": [_vp, _u32, _vp, _vp],

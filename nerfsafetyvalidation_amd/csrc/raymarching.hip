@@ -581,7 +581,31 @@ __global__ void __launch_bounds__(1024) k_get_rays_backward(const float* __restr
 
 using namespace ngp;
 
+// the two lines that end run_cuda (renderer.py:376-381; torch ops, one rounding each, in this order):
+//   image = image + (1 - weights_sum)[:, None] * bg_color        depth = clamp(depth - nears, min = 0) / (fars - nears)
+__global__ void __launch_bounds__(kBlock) k_finish_rays(float* __restrict__ image, float* __restrict__ depth, const float* __restrict__ weights_sum,
+                                                        const float* __restrict__ nears, const float* __restrict__ fars, float bg_r, float bg_g,
+                                                        float bg_b, uint32_t N) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float t = 1.0f - weights_sum[n];
+    image[(size_t)n * 3] = image[(size_t)n * 3] + t * bg_r;
+    image[(size_t)n * 3 + 1] = image[(size_t)n * 3 + 1] + t * bg_g;
+    image[(size_t)n * 3 + 2] = image[(size_t)n * 3 + 2] + t * bg_b;
+    const float d = depth[n] - nears[n];
+    depth[n] = (d != d ? d : fmaxf(d, 0.0f)) / (fars[n] - nears[n]);       // (torch.clamp hands a NaN on)
+}
+
 extern "C" {
+
+int ngp_finish_rays(float* image, float* depth, const float* weights_sum, const float* nears, const float* fars, const float* bg_color3,
+                    uint32_t N, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(image && depth && weights_sum && nears && fars && bg_color3, "finish_rays: null pointer");
+    k_finish_rays<<<div_up(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(image, depth, weights_sum, nears, fars, bg_color3[0], bg_color3[1],
+                                                                          bg_color3[2], N);
+    return check_launch("finish_rays");
+}
 
 int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near, float* nears,
                            float* fars, ngp_stream_t stream) {

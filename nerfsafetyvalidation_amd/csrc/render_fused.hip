@@ -81,6 +81,9 @@ constexpr uint32_t kSpecMaxQ = 8;
 constexpr uint32_t kSpecMaxSamples = 32;  // samples per ray and launch in the n_step >= 5 regimes
 constexpr uint32_t kSpecSafetyX2 = 3;     // later launches: sized for kSpecSafetyX2 / 2 = 1.5 x the recent death rate
 constexpr int kDeathShards = 64;
+// per launch parity: [kDeathShards][kSpecK] deaths per iteration (k_render_iter) | [kDeathShards][kSpecK] rays whose MARCH runs out of
+// samples in that iteration (k_march_ahead: known before the network runs, see truncate_launch)
+constexpr uint32_t kDeathWords = 2u * kDeathShards * kSpecK;
 // work-queue heads: one per shard (chunk c belongs to shard c & 7), each on its own 128-byte line, two sets (ping-pong with Ctl)
 struct QueueHeads { uint32_t head[8][32]; };
 
@@ -2120,7 +2123,49 @@ struct RenderArgs {
     // sample index are 512 contiguous bytes), and per list entry the number of samples marched (bits 0-5) + the slow-ray flag (bit 7)
     float2* march_samples;
     uint8_t* march_counts;
+    uint32_t wave_slots;              // waves the chip holds for this launch (item_width)
+    uint32_t n_rays;                  // N: the reference's n_step = clamp(N // n_alive, 1, 8)
+    uint32_t pre_verdict;             // k_march_ahead counts the rays whose march runs out per iteration (truncate_launch); 0: diagnostics
 };
+
+// Work items of k_render_iter: W consecutive entries of the alive list, one wave each.  64 while the list fills the chip's wave slots
+// (every lane of the per-ray phases busy); 32 / 16 once it no longer does -- the late iterations of a frame, and most of a frame whose
+// rays mostly miss the scene (BASELINE configs[3]: cameras outside the box): a launch then lasts as long as ONE item's sub-passes, and
+// narrower items spread the same tiles over four times the waves.  The tile phases are 16 samples wide either way.  Both kernels of
+// a launch derive W from the launch's n_alive.
+__host__ __device__ __forceinline__ uint32_t item_width(uint32_t n_alive, uint32_t wave_slots) {
+    return n_alive >= 64u * wave_slots ? 64u : (n_alive >= 32u * wave_slots ? 32u : 16u);
+}
+// A multi-iteration launch that cannot pass its verification is cut short BEFORE the network runs.  k_march_ahead knows, for every
+// ray, in which of the launch's iterations its march runs out of samples (the ray dies there at the latest): those counts are a lower
+// bound of the deaths per iteration, and N // n_alive only grows as rays die, so an iteration whose n_step already differs from q
+// under the lower bound differs for certain.  The launch then covers the iterations before it (one iteration: an ordinary launch);
+// k_render_iter and k_render_compact both apply this to their copy of the launch's Ctl, from the same counts.  Cameras outside the
+// scene box (BASELINE configs[3]) lose most rays in the first iteration: without this the first launch of every frame ran the
+// network on up to eight samples per ray, failed its verification and was run again.
+// `exhausted[j]`: rays whose march ends in iteration j of the launch (summed over the shards).
+__device__ __forceinline__ void truncate_launch(Ctl& c, const uint32_t* exhausted, uint32_t N) {
+    if (!c.spec) return;
+    const uint32_t q = c.spec, K = c.n_step / q;
+    uint32_t alive = c.n_alive, ok = K;
+    for (uint32_t j = 0; j < K; j++) {
+        if (alive == 0) break;                                    // (the reference stops here: nothing left to violate)
+        const uint32_t want_q = N / alive;
+        if (j > 0 && (want_q < 1 ? 1u : (want_q > 8 ? 8u : want_q)) != q) { ok = j; break; }
+        alive -= exhausted[j] < alive ? exhausted[j] : alive;
+    }
+    if (ok < K) {
+        if (ok <= 1) { c.spec = 0; c.n_step = q; }
+        else c.n_step = ok * q;
+        c.rsv += 1;                                               // (diagnostics: launches cut short)
+    }
+}
+// an upper bound of the items of a launch whose n_alive is at most `ub`
+static uint32_t items_bound(uint32_t ub, uint32_t wave_slots) {
+    const uint32_t by64 = div_up(ub ? ub : 1, 64), narrow = div_up(ub ? ub : 1, 16);
+    const uint32_t cap = 2u * wave_slots + 1u;                 // W < 64 only below 64 * wave_slots entries: at most this many items
+    return by64 > (narrow < cap ? narrow : cap) ? by64 : (narrow < cap ? narrow : cap);
+}
 
 struct WaveSlab {  // per-wave LDS: kCh march steps of 64 rays
     float t[kSlots], dt[kSlots], sig[kSlots];
@@ -2197,6 +2242,16 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
     // Rays whose next march begins inside an empty 4x4x4 block are about to skip through empty space (tens of DDA probes) while the
     // others take one probe per sample: k_render_iter groups them into their own chunks (a scheduling decision only).  The flag is
     // meaningful for rays that complete all n_step samples -- the survivors -- whose rays_t then is geo_tc.
+    if (spec && ra.pre_verdict) {     // the iteration of this launch in which the ray's march runs out (truncate_launch); wave-aggregated, sharded counters
+        const uint32_t K = n_step / spec, jd = emitted < n_step ? emitted / spec : 0xFFFFFFFFu;
+        const unsigned long long act = __ballot(true);
+        const bool leader = (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act);
+        uint32_t* ex = ra.death_shards + (size_t)kDeathShards * kSpecK + (blockIdx.x % kDeathShards) * kSpecK;
+        for (uint32_t j = 0; j < K; j++) {
+            const unsigned long long b = __ballot(jd == j);
+            if (leader && b) atomicAdd(&ex[j], (uint32_t)__popcll(b));
+        }
+    }
     bool slow = false;
     if (ra.sort_slow && emitted == n_step) slow = geo_tc < far && (LIN ? dda.coarse_empty_at_lin(geo_tc, coarse) : dda.coarse_empty_at(geo_tc, coarse));
     ra.march_counts[entry] = (uint8_t)(emitted | (slow ? 128u : 0u));
@@ -2204,13 +2259,27 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
 
 template <int MODE, bool HACC = false>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs na, GridLevels lv, RenderArgs ra) {
-    const Ctl ctl = *ra.ctl;
+    Ctl ctl = *ra.ctl;
     if (ctl.done) return;
+    const uint32_t n_step_marched = ctl.n_step;     // k_march_ahead's buffer is laid out for the launch as it was planned
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ctl.spec) {
+        // (in the dynamic allocation, which is sized up to the CU's whole LDS: the weights' place, before stage_block fills it)
+        uint32_t* exhausted = reinterpret_cast<uint32_t*>(smem);
+        if (threadIdx.x < kSpecK) {
+            uint32_t d = 0;
+            for (int sh = 0; sh < kDeathShards; sh++) d += ra.death_shards[(size_t)kDeathShards * kSpecK + sh * kSpecK + threadIdx.x];
+            exhausted[threadIdx.x] = d;
+        }
+        __syncthreads();
+        truncate_launch(ctl, exhausted, ra.n_rays);
+        __syncthreads();
+    }
     const uint32_t n_alive = ctl.n_alive, n_step = ctl.n_step;
     const uint32_t spec = ctl.spec;    // != 0: the launch covers n_step / spec reference iterations of `spec` samples each (see Ctl)
-    const uint32_t n_chunks = (n_alive + 63) / 64;
+    const uint32_t W = item_width(n_alive, ra.wave_slots);
+    const uint32_t n_chunks = (n_alive + W - 1) / W;        // work items (see item_width)
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t w_bytes = net_w_bytes_f16(na);
     _Float16* Wlds = reinterpret_cast<_Float16*>(smem);
     LevelTab* lt = reinterpret_cast<LevelTab*>(smem + w_bytes);
@@ -2245,8 +2314,10 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         if (chunk == 0xFFFFFFFFu) break;
         if (ra.stamps) ts0 = __builtin_amdgcn_s_memtime();
 
-        const uint32_t entry = chunk * 64 + lane;
-        const bool active = entry < n_alive;
+        // the item's W entries keep their lanes of the 64-entry group they belong to (k_march_ahead's layout): lanes outside are idle
+        const uint32_t first_entry = chunk * W, group = first_entry >> 6;
+        const uint32_t entry = group * 64 + lane;
+        const bool active = entry < n_alive && entry - first_entry < W;
         const int32_t ray = active ? ra.alive_in[entry] : -1;
 
         float last_t = 0, t_c = 0, t_c0 = 0, t_start = 0;
@@ -2276,7 +2347,7 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
                 ra.backup[(size_t)ray * 2 + 1] = make_float4(cr, cg, cb, 0.0f);
             }
         }
-        const float2* marched = ra.march_samples + ((size_t)chunk * n_step) * 64 + lane;
+        const float2* marched = ra.march_samples + ((size_t)group * n_step_marched) * 64 + lane;
         // ray states: running -> (terminated by T < 1e-4 | exhausted: the march ran out of samples) -> dead
         bool running = active;
         uint32_t steps_done = 0;      // samples composited so far (== n_step at the end <=> the ray survives)
@@ -2450,8 +2521,8 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
         const bool slow = ra.sort_slow && survive && slow_next;      // (k_march_ahead looked the ray's next start position up)
         const unsigned long long ball_f = __ballot(survive && !slow), ball_s = __ballot(survive && slow);
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        if (survive && !slow) ra.staging[(size_t)chunk * 64 + (uint32_t)__popcll(ball_f & lt_mask)] = ray;
-        if (survive && slow) ra.staging[(size_t)chunk * 64 + 63 - (uint32_t)__popcll(ball_s & lt_mask)] = ray;   // filled from the back
+        if (survive && !slow) ra.staging[(size_t)first_entry + (uint32_t)__popcll(ball_f & lt_mask)] = ray;
+        if (survive && slow) ra.staging[(size_t)first_entry + W - 1 - (uint32_t)__popcll(ball_s & lt_mask)] = ray;   // filled from the back
         if (lane == 0) ra.chunk_count[chunk] = (uint32_t)__popcll(ball_f) | ((uint32_t)__popcll(ball_s) << 16);
         if (spec) {
             // a ray that completed m samples died in the launch's m-th iteration: the n_alive sequence follows from these counts.
@@ -2508,10 +2579,10 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
                                                          const uint32_t* __restrict__ death_shards, uint32_t spec_allowed, const int32_t* __restrict__ alive_in,
                                                          const float4* __restrict__ backup, float* __restrict__ rays_t, float* __restrict__ weights_sum,
                                                          float* __restrict__ depth, float* __restrict__ image, uint32_t* __restrict__ sample_hash,
-                                                         unsigned long long* stat_shards_rw, uint32_t* __restrict__ death_next) {
+                                                         unsigned long long* stat_shards_rw, uint32_t* __restrict__ death_next, uint32_t wave_slots) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
-    const Ctl c = *cur;
+    Ctl c = *cur;
     if (c.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             *nxt = c;
@@ -2519,21 +2590,27 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         }
         return;
     }
-    const uint32_t n_chunks = (c.n_alive + 63) / 64;
+    const uint32_t W = item_width(c.n_alive, wave_slots);
+    const uint32_t n_chunks = (c.n_alive + W - 1) / W;      // k_render_iter's work items
     const uint32_t n_blocks = (n_chunks + 7) / 8;
     const uint32_t g = blockIdx.x;
     if (g >= n_blocks) return;
     const uint32_t first = g * 8;
     // ---- a launch that covered several reference iterations is verified first (every block reaches the same verdict) ----
-    __shared__ uint32_t deaths[kSpecK];
+    __shared__ uint32_t deaths[kSpecK], exhausted[kSpecK];
     __shared__ uint32_t verdict_bad;
     if (threadIdx.x < kSpecK) {
-        uint32_t d = 0;
+        uint32_t d = 0, x = 0;
         if (c.spec)
-            for (int sh = 0; sh < kDeathShards; sh++) d += death_shards[sh * kSpecK + threadIdx.x];
+            for (int sh = 0; sh < kDeathShards; sh++) {
+                d += death_shards[sh * kSpecK + threadIdx.x];
+                x += death_shards[(size_t)kDeathShards * kSpecK + sh * kSpecK + threadIdx.x];
+            }
         deaths[threadIdx.x] = d;
+        exhausted[threadIdx.x] = x;
     }
     __syncthreads();
+    truncate_launch(c, exhausted, N);          // the launch k_render_iter actually ran (same counts, same cut)
     if (threadIdx.x == 0) {
         // K = c.n_step / q reference iterations of q = c.spec samples each: n_alive(i + j) = n_alive(i) - deaths before j.  Each must
         // have been run with n_step = clamp(N // n_alive, 1, 8) == q, and the loop would have stopped at the first empty list.
@@ -2556,7 +2633,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
     if (verdict_bad) {
         // ROLLBACK: the launch was not equivalent to the reference's iterations.  Every ray it processed gets the state it
         // started from back, the alive list is handed on unchanged, and the iteration is run again on its own.
-        for (uint32_t e = first * 64 + threadIdx.x; e < (first + 8) * 64 && e < c.n_alive; e += 256) {
+        for (uint32_t e = first * W + threadIdx.x; e < (first + 8) * W && e < c.n_alive; e += 256) {
             const int32_t ray = alive_in[e];
             const float4 a = backup[(size_t)ray * 2], b = backup[(size_t)ray * 2 + 1];
             rays_t[ray] = a.x; weights_sum[ray] = a.y; depth[ray] = a.z;
@@ -2612,8 +2689,8 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         const uint32_t ci = w * 2 + h;
         const uint32_t nf = off_f[ci + 1] - off_f[ci], ns = off_s[ci + 1] - off_s[ci];
         // slow rays go FIRST: their chunks are the long jobs and must not form the tail of the work queue
-        if (lane < ns) alive_out[prefix_s + off_s[ci] + lane] = staging[(size_t)(first + ci) * 64 + 63 - lane];
-        if (lane < nf) alive_out[total_s + prefix_f + off_f[ci] + lane] = staging[(size_t)(first + ci) * 64 + lane];
+        if (lane < ns) alive_out[prefix_s + off_s[ci] + lane] = staging[(size_t)(first + ci) * W + W - 1 - lane];
+        if (lane < nf) alive_out[total_s + prefix_f + off_f[ci] + lane] = staging[(size_t)(first + ci) * W + lane];
     }
     unsigned long long marched = threadIdx.x < (uint32_t)kStatShards ? stat_shards_rw[threadIdx.x] : 0ull;   // kStatShards == 64: wave 0
 #pragma unroll
@@ -2678,7 +2755,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             if (K >= 2) { n.spec = q; n.n_step = K * q; }
         }
         if (n.spec)   // the next launch counts deaths per iteration: its buffer (not the one this kernel's blocks are reading) starts at zero
-            for (int i = 0; i < kDeathShards * (int)kSpecK; i++) death_next[i] = 0;
+            for (uint32_t i = 0; i < kDeathWords; i++) death_next[i] = 0;
         *nxt = n;
         for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
         publish_status(host_slot, n, seq);
@@ -2693,7 +2770,7 @@ __global__ void __launch_bounds__(256) k_render_init(uint32_t N, const float* __
                                                       uint32_t tile_w) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n < (uint32_t)kStatShards) stat_shards[n] = 0ull;
-    if (n < 2u * (uint32_t)kDeathShards * kSpecK) death_shards[n] = 0;   // both buffers (launches alternate between them)
+    if (n < 2u * kDeathWords) death_shards[n] = 0;   // both buffers (launches alternate between them)
     if (n < 16) heads[n >> 3].head[n & 7][0] = 0;
     if (n < N) {
         if (sample_hash) sample_hash[n] = 2166136261u;
@@ -2842,6 +2919,8 @@ struct DebugState {
     bool jump_off() const { return (flags & 1) != 0; }
     bool spec_off() const { return (flags & 256) != 0; }
     bool tile_off() const { return (flags & 8192) != 0; }
+    bool pre_verdict_off() const { return (flags & 16384) != 0; }
+    bool narrow_items_off() const { return (flags & 32768) != 0; }
     uint32_t spec_safety_x2() const { return ((uint32_t)flags >> 9) & 15u; }   // 0: kSpecSafetyX2
     uint32_t shrink() const { return ((uint32_t)flags >> 4) & 15u; }
 };
@@ -2987,15 +3066,22 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
     c->max_rays = max_rays;
     const size_t chunks = div_up(max_rays, 64);
     bool ok = true;
+    int cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    const size_t max_items = items_bound(max_rays, (uint32_t)cus * 16u) + 8;
     ok &= hipMalloc(&c->alive[0], (size_t)max_rays * 4) == hipSuccess;
     ok &= hipMalloc(&c->alive[1], (size_t)max_rays * 4) == hipSuccess;
     ok &= hipMalloc(&c->staging, chunks * 64 * 4) == hipSuccess;
-    ok &= hipMalloc(&c->chunk_count, chunks * 4) == hipSuccess;
+    ok &= hipMalloc(&c->chunk_count, (max_items > (size_t)div_up(max_rays, 256) ? max_items : (size_t)div_up(max_rays, 256)) * 4) == hipSuccess;
     ok &= hipMalloc(&c->rays_t, (size_t)max_rays * 4) == hipSuccess;
     ok &= hipMalloc(&c->coarse, kCoarseMaxBytes) == hipSuccess;
     ok &= hipMalloc(&c->ctl, 2 * sizeof(Ctl)) == hipSuccess;
     ok &= hipMalloc(&c->stat_shards, kStatShards * sizeof(unsigned long long)) == hipSuccess;
-    ok &= hipMalloc(&c->death_shards, 2 * (size_t)kDeathShards * kSpecK * sizeof(uint32_t)) == hipSuccess;   // two buffers, by launch parity
+    ok &= hipMalloc(&c->death_shards, 2 * (size_t)kDeathWords * sizeof(uint32_t)) == hipSuccess;   // two buffers, by launch parity
     ok &= hipMalloc(&c->backup, (size_t)max_rays * 2 * sizeof(float4)) == hipSuccess;
     // (n_alive * n_step <= 8 N in every regime of the schedule: n_step <= 8 while more than N / 5 rays live, <= 32 below that)
     ok &= hipMalloc(&c->march_samples, ((size_t)max_rays + 64) * 8 * sizeof(float2)) == hipSuccess;
@@ -3071,7 +3157,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const uint32_t fw = ctx->frame_width;
     const uint32_t tile_w = (perturb == 0 && !dbg.tile_off() && fw >= 4 && fw % 4 == 0 && N % (4 * fw) == 0) ? fw : 0u;
     // (the grid also has to cover the loop's own counters -- both death-count buffers -- however few rays there are)
-    const uint32_t init_threads = N > 2u * kDeathShards * kSpecK ? N : 2u * kDeathShards * kSpecK;
+    const uint32_t init_threads = N > 2u * kDeathWords ? N : 2u * kDeathWords;
     k_render_init<<<div_up(init_threads, 256), 256, 0, s>>>(N, nears, ctx->rays_t, ctx->alive[0], weights_sum, depth, image, ctx->ctl, max_steps,
                                                  dbg.sample_hash, ctx->stat_shards, ctx->heads, ctx->death_shards, spec_allowed, tile_w);
 
@@ -3081,10 +3167,17 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     ra.last_sigmas = last_sigmas; ra.last_rgbs = last_rgbs;
     if (pad_value_host) { ra.pad_sigma = pad_value_host[0]; ra.pad_r = pad_value_host[1]; ra.pad_g = pad_value_host[2]; ra.pad_b = pad_value_host[3]; }
     ra.staging = ctx->staging; ra.chunk_count = ctx->chunk_count; ra.stat_shards = ctx->stat_shards;
+    {
+        static const char* env = getenv("NGP_ITEM_SLOTS");       // diagnostics (A/B timing): 0 = 64-entry items always
+        ra.wave_slots = dbg.narrow_items_off() ? 0u : (env ? (uint32_t)atoi(env) : (uint32_t)ctx->num_cu * 16u);
+        static const bool no_pre = getenv("NGP_NO_PRE_VERDICT") != nullptr;   // diagnostics: every multi-iteration launch runs as planned
+        ra.pre_verdict = (no_pre || dbg.pre_verdict_off()) ? 0u : 1u;
+    }
     ra.backup = ctx->backup;
     ra.march_samples = ctx->march_samples; ra.march_counts = ctx->march_counts;
     ra.bitfield = model->density_bitfield; ra.cascade = model->cascade; ra.grid_size = model->grid_size;
     ra.max_steps = max_steps; ra.perturb = perturb; ra.dt_gamma = dt_gamma;
+    ra.n_rays = N;
     ra.rng.seed((uint64_t)perturb);  // raymarching.cu:819
     ra.stamps = dbg.stamps;
     ra.sort_slow = (perturb == 0 && !dbg.sort_off()) ? 1u : 0u;   // needs the coarse filter; checked below
@@ -3151,14 +3244,14 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     bool done = false;
     while (!done) {
         const uint32_t cur = launched & 1;
-        const uint32_t chunks = div_up(ub ? ub : 1, 64);
+        const uint32_t chunks = items_bound(ub, ra.wave_slots);     // work items of the launch, at most
         const uint32_t max_blocks = (uint32_t)ctx->num_cu * blocks_per_cu;   // persistent: resident workgroups pull chunks from a queue
         const uint32_t want_blocks = div_up(chunks, kWaves);
         const uint32_t blocks = want_blocks < max_blocks ? want_blocks : max_blocks;
         ra.alive_in = ctx->alive[cur];
         ra.ctl = ctx->ctl + cur;
         ra.heads = ctx->heads + cur;
-        ra.death_shards = ctx->death_shards + (size_t)cur * kDeathShards * kSpecK;
+        ra.death_shards = ctx->death_shards + (size_t)cur * kDeathWords;
         {
             ProfScope pm("k_march_ahead", s, 0);  // per-launch events only when ngp_prof_enable(1)
             if (lin) k_march_ahead<true><<<div_up(ub ? ub : 1, 256), 256, 0, s>>>(ra, na.bound);
@@ -3171,9 +3264,9 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         k_render_compact<<<div_up(chunks, 8), 256, 0, s>>>(ctx->ctl + cur, ctx->ctl + (cur ^ 1), ctx->staging, ctx->chunk_count,
                                                            ctx->alive[cur ^ 1], N, max_steps, ctx->stat_shards, ctx->heads + (cur ^ 1),
                                                            ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1,
-                                                           ctx->death_shards + (size_t)cur * kDeathShards * kSpecK, spec_allowed, ctx->alive[cur],
+                                                           ctx->death_shards + (size_t)cur * kDeathWords, spec_allowed, ctx->alive[cur],
                                                            ctx->backup, ctx->rays_t, weights_sum, depth, image, dbg.sample_hash, ctx->stat_shards,
-                                                           ctx->death_shards + (size_t)(cur ^ 1) * kDeathShards * kSpecK);
+                                                           ctx->death_shards + (size_t)(cur ^ 1) * kDeathWords, ra.wave_slots);
         launched++;
         launches += 3;
         // consume every status that has already landed; block only when too far ahead

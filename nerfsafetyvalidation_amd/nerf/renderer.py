@@ -198,6 +198,22 @@ class NeRFRenderer(nn.Module):
             return self.background(raymarching.sph_from_ray(origins, directions, self.bg_radius), directions)
         return 1 if bg_color is None else bg_color
 
+    @staticmethod
+    def _constant_backdrop(backdrop):
+        """three host floats if the backdrop is one colour for every ray (a Python number, or a 1- / 3-element host tensor or sequence)"""
+        import ctypes as C
+        if isinstance(backdrop, (int, float)):
+            vals = [float(backdrop)] * 3
+        elif isinstance(backdrop, torch.Tensor):
+            if backdrop.is_cuda or backdrop.numel() not in (1, 3) or backdrop.requires_grad:
+                return None
+            vals = [float(v) for v in backdrop.reshape(-1).tolist()] * (3 // backdrop.numel())
+        elif isinstance(backdrop, (tuple, list)) and len(backdrop) in (1, 3) and all(isinstance(v, (int, float)) for v in backdrop):
+            vals = [float(v) for v in backdrop] * (3 // len(backdrop))
+        else:
+            return None
+        return (C.c_float * 3)(*vals)
+
     def _march_train(self, origins, directions, nears, fars, dt_gamma, max_steps, perturb, force_all_rays):
         """training branch (renderer.py:286-327): one march over all rays, one network call, one differentiable compositing"""
         counter = self.step_counter[self.local_step % 16]      # ring of the last 16 steps' sample counts (-> mean_count)
@@ -260,8 +276,15 @@ class NeRFRenderer(nn.Module):
                 self.last_render_stats = fm.last_stats
             else:
                 acc, depth, image, sigmas, rgbs = self._march_eval_operators(origins, directions, nears, fars, dt_gamma, max_steps, perturb)
-        image = image + (1 - acc).unsqueeze(-1) * backdrop
-        depth = (depth - nears).clamp(min=0) / (fars - nears)    # renderer.py:326 / :376
+        bg3 = self._constant_backdrop(backdrop)
+        if bg3 is not None and not self.training and not torch.is_grad_enabled() and image.is_cuda and image.dtype == torch.float32:
+            # the two lines below in one launch, in place (image / depth are this call's own tensors): same operations, same roundings
+            image, depth, acc = image.contiguous(), depth.contiguous(), acc.contiguous()
+            _lib.check(_lib.lib().ngp_finish_rays(_lib.ptr(image), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(nears.contiguous()),
+                                                  _lib.ptr(fars.contiguous()), bg3, image.shape[0], _lib.stream()), "finish_rays")
+        else:
+            image = image + (1 - acc).unsqueeze(-1) * backdrop
+            depth = (depth - nears).clamp(min=0) / (fars - nears)    # renderer.py:326 / :376
         out.update(depth=depth.view(*prefix), image=image.view(*prefix, 3), sigmas=sigmas, rgbs=rgbs)
         return out
 

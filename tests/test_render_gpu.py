@@ -331,6 +331,61 @@ def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
         assert outs[0][1][key] == outs[256][1][key], key
 
 
+def test_launch_cut_short_before_the_network_and_narrow_work_items(device):
+    """Cameras outside the scene box (BASELINE configs[3]): most rays find no sample and die in the first iteration, so the first
+    multi-iteration launch cannot pass its verification.  k_march_ahead's per-iteration counts of rays whose march runs out cut the
+    launch short BEFORE the network runs (no replay); the late, thinly populated launches use 32- / 16-entry work items.  Neither
+    changes a result: image, depth, schedule counters and the per-ray sample hashes equal those of the plain configuration."""
+    from nerfsafetyvalidation_amd import _lib
+    from nerfsafetyvalidation_amd.scene import StonehengeScene
+    sc = StonehengeScene(H=200, W=200, bound=1, radius=3.2)
+    model = sc.build_model(device)
+    lib = _lib.lib()
+    ro, rd = Hh.pinhole_rays(sc.poses[63], sc.intrinsics, sc.H, sc.W)
+    N = ro.shape[0]
+    outs = {}
+    try:
+        for flags in (0, 16384, 32768, 16384 | 32768 | 256):
+            lib.ngp_debug_disable_march_queue(flags)
+            hashes = torch.zeros(N, dtype=torch.int32, device=device)
+            lib.ngp_debug_set_sample_hash(hashes.data_ptr())
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                out = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False)
+            torch.cuda.synchronize()
+            lib.ngp_debug_set_sample_hash(None)
+            outs[flags] = (out["image"].float().clone(), out["depth"].float().clone(), hashes.clone(), dict(model.last_render_stats))
+    finally:
+        lib.ngp_debug_set_sample_hash(None)
+        lib.ngp_debug_disable_march_queue(0)
+    ref = outs[16384 | 32768 | 256]                                  # one iteration per launch, 64-entry items
+    assert ref[3]["replayed"] == 0
+    assert outs[16384][3]["replayed"] >= 1                           # as planned: the first launch fails its verification
+    assert outs[0][3]["replayed"] < outs[16384][3]["replayed"]      # cut short instead
+    for flags in (0, 16384, 32768):
+        got = outs[flags]
+        # (depth is 0 / 0 = NaN on the rays that miss the box, renderer.py:381)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1].nan_to_num(nan=-7.0), ref[1].nan_to_num(nan=-7.0)) and torch.equal(got[2], ref[2]), flags
+        for key in ("samples_marched", "samples_slots", "iterations"):
+            assert got[3][key] == ref[3][key], (flags, key)
+    assert float((ref[0] != 1).float().mean()) > 0.02                # the object is in view
+
+
+def test_finish_rays_equals_the_torch_lines(setup, device):
+    """run_cuda's last two lines (renderer.py:376-381: background mix, depth normalisation) as one in-place launch against the torch
+    ops, which a per-ray backdrop tensor still takes: bit-identical image and depth, NaNs (rays that miss the box: 0 / 0) included."""
+    sc, model = setup[0], setup[1]
+    ro, rd = Hh.pinhole_rays(sc.poses[12], sc.intrinsics, sc.H, sc.W)
+    ro[:5] += 50.0                                                   # rays that start far outside and miss the box
+    N = ro.shape[0]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=(0.25, 0.5, 1.0), perturb=False)
+        b = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=torch.tensor([0.25, 0.5, 1.0], device=device).expand(N, 3), perturb=False)
+    assert torch.equal(a["image"], b["image"])
+    da, db = a["depth"], b["depth"]
+    assert torch.equal(torch.isnan(da), torch.isnan(db)) and torch.equal(da[~torch.isnan(da)], db[~torch.isnan(db)])
+    assert float((a["image"].reshape(-1, 3)[:, 2] == 1.0).float().mean()) > 0.001     # some pixels show the backdrop only
+
+
 def test_linear_backbone_fused_vs_operator_loop(device):
     """nerf/network.py backbone (nn.Linear under autocast = library GEMMs) vs the fused kernel fed its padded weights"""
     sc = _scene()
