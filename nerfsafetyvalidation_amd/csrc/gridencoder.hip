@@ -59,6 +59,26 @@ __device__ __forceinline__ uint32_t grid_entry(uint32_t gridtype, bool align_cor
     return index % hashmap_size;
 }
 
+// The same index from what fill_levels worked out once per level on the host (GridLevels: the strides of the dimensions the :58-62
+// loop consumes -- 0 for the others --, whether the level is hashed, and how the final `% hashmap_size` acts: not at all on a dense
+// level, as a mask on a power-of-two size, as a real modulo otherwise).  `level` is wave-uniform: the recipe is scalar, and the common
+// cases carry no integer division (a 32-bit modulo is ~35 vector instructions on gfx950 -- eight per point and level in every kernel
+// of this file until round 3: most of their instruction count).
+template <int D>
+__device__ __forceinline__ uint32_t grid_entry_lv(const GridLevels& lv, uint32_t level, uint32_t hashmap_size, const uint32_t (&p)[D]) {
+    uint32_t index;
+    if (lv.hashed[level]) {
+        index = fast_hash<D>(p);
+    } else {
+        index = p[0] + p[1] * lv.mul1[level];
+        if constexpr (D == 3) index += p[2] * lv.mul2[level];
+    }
+    const uint32_t mode = lv.mode[level];
+    if (mode == 1) index &= hashmap_size - 1u;
+    else if (mode == 2) index %= hashmap_size;
+    return index;
+}
+
 // acc += w * g with the reference's scalar_t semantics (c10::Half arithmetic, gridencoder.cu:169-172):
 // f32: one fma; f16: product rounded to half, then a half add.
 __device__ __forceinline__ void acc_mul(float& acc, float w, float g) { acc = fmaf(w, g, acc); }
@@ -96,7 +116,6 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
     const T* tab = grid + (size_t)lv.offset[level] * C;
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
     const float scale = lv.scale[level];
-    const uint32_t resolution = lv.resolution[level];
 
     float in[D];
     bool oob = false;
@@ -136,7 +155,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
         uint32_t pl[D];
 #pragma unroll
         for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
-        const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+        const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
         corner[idx] = *reinterpret_cast<const V*>(tab + (size_t)e * C);
     }
 
@@ -251,12 +270,12 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
             raw[i][0] = lo.x; raw[i][1] = lo.y; raw[i][2] = lo.z; raw[i][3] = lo.w;
             raw[i][4] = hi.x; raw[i][5] = hi.y; raw[i][6] = hi.z; raw[i][7] = hi.w;
         } else {
-            const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level], resolution = lv.resolution[level];
+            const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
             const uint32_t* tab = tab32 + lv.offset[level];
 #pragma unroll
             for (int idx = 0; idx < 8; idx++) {
                 const uint32_t pl[D] = {pg[0] + (idx & 1), pg[1] + ((idx >> 1) & 1), pg[2] + ((idx >> 2) & 1)};
-                raw[i][idx] = tab[grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl)];
+                raw[i][idx] = tab[grid_entry_lv<D>(lv, level, hashmap_size, pl)];
             }
         }
     }
@@ -389,7 +408,6 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restric
     if (pb * kGridBlock >= B) return;            // (whole blocks only: every lane of a live wave takes part in the shuffles)
     T* tab = grad_grid + (size_t)lv.offset[level] * C;
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
-    const uint32_t resolution = lv.resolution[level];
     float pos[D];
     uint32_t pg[D];
     bool valid = locate<T, D>(inputs, b, B, lv.scale[level], align_corners, pos, pg);
@@ -414,7 +432,7 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restric
             w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
             pl[d] = pg[d] + ((idx >> d) & 1);
         }
-        const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+        const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
         float v[C];
 #pragma unroll
         for (int c = 0; c < C; c++) v[c] = w * g[c];
@@ -485,7 +503,6 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
         }
     T* tab = grad_grid + (size_t)lv.offset[level] * C;
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
-    const uint32_t resolution = lv.resolution[level];
     const uint32_t n = hashmap_size * C;
     for (uint32_t i = threadIdx.x; i < n; i += kSmallThreads) acc[i] = 0ull;
     __syncthreads();
@@ -521,7 +538,7 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
                 uint32_t pl[D];
 #pragma unroll
                 for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
-                const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+                const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
 #pragma unroll
                 for (int c = 0; c < C; c++) {
                     if constexpr (sizeof(T) == 2) {
@@ -615,7 +632,7 @@ constexpr float kMergeScale = 0x1p26f, kMergeInvScale = 0x1p-26f;
 template <int D, int NT, bool MERGE>
 __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict__ grad, const float* __restrict__ inputs,
                                                      _Float16* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype,
-                                                     bool align_corners, BinLevels bl, uint32_t first, BinPlan plan, GridIo io) {
+                                                     bool align_corners, BinLevels bl, uint32_t first, BinPlan plan, GridIo io, uint32_t dbg_skip = 0) {
     constexpr int C = 2, NC = 1 << D;
     constexpr uint32_t RC = MERGE ? NT * NC / 2 : NT * NC;          // staged records
     constexpr int TPS = MERGE ? (int)((kMergeSlots + NT - 1) / NT) : 1;     // table slots per thread
@@ -626,7 +643,6 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
     const uint32_t level = bl.level[first + blockIdx.y];
     _Float16* tab = grad_grid + (size_t)lv.offset[level] * C;
     const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
-    const uint32_t resolution = lv.resolution[level];
     const bool hashed = lv.hashed[level] != 0;
     const uint32_t n_bins = kBinMax;
     const uint32_t cap = region_cap(plan.level_records, n_bins);
@@ -660,7 +676,7 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
         v[idx * 2] = w * g[0]; v[idx * 2 + 1] = w * g[1];
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const bool tail = merge_cell_rows<D>(valid, pg, v);
+    const bool tail = (dbg_skip & 8u) ? valid : merge_cell_rows<D>(valid, pg, v);
     auto to_half2 = [](float a, float c) {
         const __half2 h = __halves2half2(__float2half_rn(a), __float2half_rn(c));
         return *reinterpret_cast<const uint32_t*>(&h);
@@ -678,7 +694,7 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
             uint32_t pl[D];
 #pragma unroll
             for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
-            const uint32_t e = grid_entry<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+            const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
             const uint32_t bin = bin_of(e, hashed);
             const uint32_t k19 = slot_of(e, hashed) | (bin << kBinLog);
             const uint32_t hv = to_half2(v[idx * 2], v[idx * 2 + 1]);
@@ -687,8 +703,8 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
                 table_add<_Float16, C>(tab, e, vv);
                 continue;
             }
-            bool in_table = false;
-            if (MERGE) {
+            bool in_table = (dbg_skip & 1u) != 0;
+            if (MERGE && !in_table) {
                 const uint32_t h = (k19 * 2654435761u) >> 22;
 #pragma unroll
                 for (uint32_t pr = 0; pr < 4 && !in_table; pr++) {
@@ -708,6 +724,8 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
             }
         }
     }
+    if (dbg_skip & 2u) return;
+    if ((dbg_skip & 4u) && !tail) return;
     uint32_t tk[TPS], tr[TPS], tv[TPS];                   // MERGE: the table slots this thread turns into records
 #pragma unroll
     for (int j = 0; j < TPS; j++) { tk[j] = kMergeEmpty; tr[j] = 0; tv[j] = 0; }
@@ -1003,6 +1021,7 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         group = group < n_bin ? group : n_bin;
         char* ws = group ? (char*)workspace : nullptr;
         if (ws) {
+            static const uint32_t dbg_skip = getenv("NGP_GRID_BWD_SKIP") ? (uint32_t)atoi(getenv("NGP_GRID_BWD_SKIP")) : 0u;
             constexpr uint32_t NT = NGP_BIN_NT;
             const uint32_t n_pb = div_up(B, NT);
             const size_t lds_bin = (size_t)NT * (1u << D) * sizeof(uint2);
@@ -1022,10 +1041,10 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
                 (void)hipMemsetAsync(plan.fill, 0, (size_t)n * kBinMax * kBinShards * kFillStride * sizeof(uint32_t), s);
                 if (merge)
                     k_grid_bwd_bin<D, NT, true><<<dim3(n_pb, n), NT, lds_merge, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype,
-                                                                                     ac, bl, first, plan, io);
+                                                                                     ac, bl, first, plan, io, dbg_skip);
                 else
                     k_grid_bwd_bin<D, NT, false><<<dim3(n_pb, n), NT, lds_bin, s>>>((const _Float16*)grad, inputs, (_Float16*)grad_emb, B, lv, gridtype,
-                                                                                    ac, bl, first, plan, io);
+                                                                                    ac, bl, first, plan, io, dbg_skip);
                 // a bin holds at most 32 regions of `cap` records: no more reducing workgroups than that can keep busy
                 uint32_t max_split = 1;
                 while (max_split < kBinSplit && (size_t)level_records / kBinMax >= (size_t)2 * max_split * kBinSplitMin) max_split *= 2;
