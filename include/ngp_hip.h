@@ -193,6 +193,10 @@ NGP_API int ngp_ffmlp_backward_planes(const uint16_t* grad, const uint16_t* inpu
                               uint32_t activation, uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                               uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
                               ngp_stream_t stream);
+/* (this build) 1 if ngp_ffmlp_backward(_planes) accepts forward_buffer == NULL for this shape: the hidden activations are then computed
+ * again from `inputs` inside the backward kernel (the forward kernel's own instruction sequence: bit-identical values), so a training
+ * forward can be an ngp_ffmlp_inference call that stores none.  64-wide networks, 2-4 layers, input_dim 32 or 64. */
+NGP_API int ngp_ffmlp_backward_recomputes(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
 NGP_API int ngp_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,

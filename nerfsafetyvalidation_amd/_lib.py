@@ -77,6 +77,7 @@ SIGNATURES = {
     "ngp_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp, _vp, _sz, _vp],
     "ngp_ffmlp_forward_planes": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "ngp_ffmlp_backward_planes": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp, _vp, _sz, _vp],
+    "ngp_ffmlp_backward_recomputes": [_u32, _u32, _u32],
     "ngp_ffmlp_backward_workspace": [_u32, _u32, _u32, _u32],
     "ngp_ffmlp_backward_buffer_bytes": [_u32, _u32, _u32, _u32],
     "ngp_ffmlp_allocate_splitk": [_sz],

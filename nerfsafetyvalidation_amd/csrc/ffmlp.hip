@@ -568,8 +568,13 @@ constexpr uint32_t kFusedTPW = 2, kFusedRows = 4 * kFusedTPW * 16;
 __device__ __forceinline__ half8v tr_pair(const _Float16* p, uint32_t stride16) {   // two 16-row tiles, k = 0..31
     return cat8(lds_tr_read(p), lds_tr_read(p + stride16));
 }
-template <int NL, bool PLANES = false, bool RELU = false>
-__global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
+// RECOMP (forward_buffer == NULL): the hidden activations are not read back but computed again from the inputs the kernel reads anyway,
+// with the forward kernel's own instruction sequence (k_ffmlp_forward_lds: same A fragments from the row-major LDS images, same B
+// fragments, same k order and accumulation order, same rounding and activation) -- bit-identical to what the forward pass would have
+// stored.  The forward pass then stores nothing (128 B per row and layer less written there, as many less read here) for 24 / 40 more
+// MFMAs per 32 rows.
+template <int NL, bool PLANES = false, bool RELU = false, bool RECOMP = false>
+__global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
                                                          const _Float16* __restrict__ weights, const _Float16* __restrict__ fwd, uint32_t B,
                                                          uint32_t in_dim, uint32_t act, _Float16* __restrict__ bwd,
                                                          _Float16* __restrict__ grad_inputs, uint32_t n_groups, float* __restrict__ ws, uint32_t P) {
@@ -589,7 +594,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
     const uint32_t n_tiles = B >> 4;
     stage_matrix(lds, W_out, 16, HID, SH);
     for (uint32_t m = 0; m < (uint32_t)NL; m++) stage_matrix(lds + off_hid + m * HID * SH, W_hid + (size_t)m * HID * HID, HID, HID, SH);
-    if (grad_inputs) stage_matrix(lds + off_in, W_in, HID, in_dim, sIn);
+    if (grad_inputs || RECOMP) stage_matrix(lds + off_in, W_in, HID, in_dim, sIn);
     __syncthreads();
     f32x4 aO = (f32x4){0, 0, 0, 0}, aH[NL][HB], aI[HB];
 #pragma unroll
@@ -616,12 +621,51 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_fused(const _Float16* __restr
 #pragma unroll
         for (int t = 0; t < (int)TPW; t++) {
             gB[t] = ld_half4(grad + row[t] * 16 + g * 4);
+            if constexpr (!RECOMP) {
 #pragma unroll
-            for (int l = (int)L - 1; l >= 0; l--)
+                for (int l = (int)L - 1; l >= 0; l--)
 #pragma unroll
-                for (int ib = 0; ib < HB; ib++) fa[l][t][ib] = ld_half4(fwd + (size_t)l * BH + row[t] * HID + ib * 16 + g * 4);
+                    for (int ib = 0; ib < HB; ib++) fa[l][t][ib] = ld_half4(fwd + (size_t)l * BH + row[t] * HID + ib * 16 + g * 4);
+            }
 #pragma unroll
             for (int ib = 0; ib < HB; ib++) xin[t][ib] = ib < (int)IB ? ld_in4<PLANES>(inputs, row[t], ib * 16 + g * 4, in_dim, B) : zero4;
+        }
+        if constexpr (RECOMP) {
+            // the forward pass again (k_ffmlp_forward_lds, layer by layer): fa[0] = act(W_in x), fa[m + 1] = act(W_hid[m] fa[m]); one tile
+            // at a time (16 accumulator registers live instead of 32: the colour net's instantiation must stay below 256 for two
+            // workgroups per CU)
+#pragma unroll
+            for (int t = 0; t < (int)TPW; t++) {
+                f32x4 acc[HB];
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) acc[ob] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) {
+                    if (kb < (int)(in_dim >> 5)) {
+                        const half8v xb = cat8(xin[t][2 * kb], xin[t][2 * kb + 1]);
+#pragma unroll
+                        for (int ob = 0; ob < HB; ob++)
+                            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_a_frag(lds + off_in, sIn, ob, kb, c, g), xb, acc[ob], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int ob = 0; ob < HB; ob++) fa[0][t][ob] = act_hidden<RELU>(act, acc[ob]);
+#pragma unroll
+                for (int m = 0; m < NL; m++) {
+                    const _Float16* Wl = lds + off_hid + m * HID * SH;
+#pragma unroll
+                    for (int ob = 0; ob < HB; ob++) acc[ob] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++) {
+                        const half8v hb = cat8(fa[m][t][2 * kb], fa[m][t][2 * kb + 1]);
+#pragma unroll
+                        for (int ob = 0; ob < HB; ob++)
+                            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_a_frag(Wl, SH, ob, kb, c, g), hb, acc[ob], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ob = 0; ob < HB; ob++) fa[m + 1][t][ob] = act_hidden<RELU>(act, acc[ob]);
+                }
+            }
         }
         half4 dh[TPW][HB];
         {
@@ -770,17 +814,13 @@ static void launch_bwd_fused(const uint16_t* grad, const uint16_t* inputs, const
                              uint32_t act, uint16_t* bwd, uint16_t* gi, float* ws, uint32_t P, hipStream_t s) {
     const size_t lds = fused_bwd_lds_bytes(in_dim, NL);
     const uint32_t n_groups = div_up(B / 16, 4 * kFusedTPW);
-    if (act == 0) {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(k_ffmlp_bwd_fused<NL, PLANES, true>), 160 * 1024);
-        k_ffmlp_bwd_fused<NL, PLANES, true><<<fused_bwd_blocks(B, in_dim, NL), 256, lds, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)w,
-                                                                                              (const _Float16*)fwd, B, in_dim, act, (_Float16*)bwd,
-                                                                                              (_Float16*)gi, n_groups, ws, P);
-    } else {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(k_ffmlp_bwd_fused<NL, PLANES, false>), 160 * 1024);
-        k_ffmlp_bwd_fused<NL, PLANES, false><<<fused_bwd_blocks(B, in_dim, NL), 256, lds, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)w,
-                                                                                               (const _Float16*)fwd, B, in_dim, act, (_Float16*)bwd,
-                                                                                               (_Float16*)gi, n_groups, ws, P);
-    }
+    typedef void (*Kern)(const _Float16*, const _Float16*, const _Float16*, const _Float16*, uint32_t, uint32_t, uint32_t, _Float16*, _Float16*, uint32_t,
+                         float*, uint32_t);
+    const Kern kern = fwd ? (act == 0 ? k_ffmlp_bwd_fused<NL, PLANES, true, false> : k_ffmlp_bwd_fused<NL, PLANES, false, false>)
+                          : (act == 0 ? k_ffmlp_bwd_fused<NL, PLANES, true, true> : k_ffmlp_bwd_fused<NL, PLANES, false, true>);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
+    kern<<<fused_bwd_blocks(B, in_dim, NL), 256, lds, s>>>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)w, (const _Float16*)fwd, B, in_dim,
+                                                           act, (_Float16*)bwd, (_Float16*)gi, n_groups, ws, P);
 }
 
 // One wave per workgroup.  blockIdx.x = batch chunk, blockIdx.y = unit: up to 4x4 output fragments of one matrix.
@@ -966,7 +1006,9 @@ static int ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const ui
         }
         return NGP_OK;
     }
-    NGP_REQUIRE(grad && inputs && weights && forward_buffer && grad_weights, "ffmlp_backward: null pointer");
+    NGP_REQUIRE(grad && inputs && weights && grad_weights, "ffmlp_backward: null pointer");
+    NGP_REQUIRE(forward_buffer || ngp_ffmlp_backward_recomputes(input_dim, hidden_dim, num_layers),
+                "ffmlp_backward: forward_buffer is NULL and this shape does not recompute the activations (ngp_ffmlp_backward_recomputes)");
     NGP_REQUIRE(!calc_grad_inputs || grad_inputs, "ffmlp_backward: calc_grad_inputs without a grad_inputs buffer");
     NGP_REQUIRE(B % 16 == 0, "ffmlp_backward: batch size must be a multiple of 16 (got %u)", B);
     NGP_REQUIRE(input_dim > 0 && input_dim % 16 == 0, "FFMLP input_dim should be 16 * m (m > 0), but got %u", input_dim);
@@ -1004,7 +1046,7 @@ static int ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const ui
     }
     NGP_REQUIRE(!planes, "ffmlp_backward: the level-major input layout is built for the 64-wide networks (2-4 layers, input_dim <= 64) with the "
                          "workspace ngp_ffmlp_backward_workspace() asks for");
-    NGP_REQUIRE(backward_buffer, "ffmlp_backward: this shape takes the two-kernel form, which needs backward_buffer");
+    NGP_REQUIRE(backward_buffer && forward_buffer, "ffmlp_backward: this shape (or workspace) takes the two-kernel form, which needs forward_buffer and backward_buffer");
     uint32_t S;
     const uint32_t chunk = splitk_plan(B, P, workspace_bytes, S);
     switch (hidden_dim) {
@@ -1058,6 +1100,10 @@ size_t ngp_ffmlp_backward_workspace(uint32_t B, uint32_t input_dim, uint32_t hid
         S = S > blocks ? S : blocks;
     }
     return (size_t)S * P * 4;
+}
+
+int ngp_ffmlp_backward_recomputes(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    return fused_bwd_applies(input_dim, hidden_dim, num_layers) && input_dim % 32 == 0 ? 1 : 0;
 }
 
 size_t ngp_ffmlp_backward_buffer_bytes(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {

@@ -13,6 +13,9 @@ from torch.amp import custom_bwd, custom_fwd
 from .. import _lib
 
 
+RECOMPUTE_ACTIVATIONS = True     # (this build; False: keep forward_buffer as the reference does -- tests compare the two)
+
+
 class _ffmlp_forward(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
@@ -29,25 +32,26 @@ class _ffmlp_forward(Function):
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         lib = _lib.lib()
         ctx.planes = planes
+        # The reference keeps every hidden layer's activations for the backward pass (forward_buffer, ffmlp.py:37-45: 128 B per row and
+        # layer written here, read there).  For the shapes whose backward kernel can compute them again from the inputs it reads anyway
+        # (ngp_ffmlp_backward_recomputes: bit-identical values) the training forward stores none -- it is the inference call.
+        keep = not inference and not (RECOMPUTE_ACTIVATIONS and lib.ngp_ffmlp_backward_recomputes(input_dim, hidden_dim, num_layers))
+        forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype) if keep else None
         if planes:
-            forward_buffer = None if inference else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             _lib.check(lib.ngp_ffmlp_forward_planes(_lib.ptr(inputs), _lib.ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
                                                     activation, output_activation, _lib.ptr(forward_buffer), _lib.ptr(outputs),
                                                     _lib.stream()), "ffmlp_forward_planes")
-            if not inference:
-                ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
-                ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
-        elif not inference:
-            forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+        elif keep:
             _lib.check(lib.ngp_ffmlp_forward(_lib.ptr(inputs), _lib.ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
                                              activation, output_activation, _lib.ptr(forward_buffer), _lib.ptr(outputs),
                                              _lib.stream()), "ffmlp_forward")
-            ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
-            ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
         else:
             _lib.check(lib.ngp_ffmlp_inference(_lib.ptr(inputs), _lib.ptr(weights), B, input_dim, output_dim, hidden_dim,
                                                num_layers, activation, output_activation, None, _lib.ptr(outputs),
                                                _lib.stream()), "ffmlp_inference")
+        if not inference:
+            ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
+            ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
         return outputs
 
     @staticmethod

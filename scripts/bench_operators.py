@@ -91,14 +91,15 @@ line("march_rays_train (two passes + ray-order offsets)", "march_rays_train", M,
 line("grid_encode_forward f16 (training batch: samples in ray order)", "grid_encode_forward", Mp, "points", 588 * Mp)
 line("sh_encode_forward deg 4", "sh_encode_forward", Mp, "points", 76 * Mp)
 line("ffmlp_forward, training (sigma 32-64-64-16 and colour 32-64-64-64-16, averaged)", "ffmlp_forward", Mp, "rows",
-     (64 + 32 + 2.5 * 128) * Mp, flops_per_call=(14336 + 22528) / 2 * Mp,
-     note="bytes: 64 in + 32 out + the stored hidden activations (2 or 3 x 128 B per row) that the backward pass reads")
+     (64 + 32) * Mp, flops_per_call=(14336 + 22528) / 2 * Mp,
+     note="bytes: 64 in + 32 out; round 3: the hidden activations are no longer stored (2 or 3 x 128 B per row until then) -- the backward "
+          "kernel computes them again from the inputs it reads anyway")
 line("composite_rays_train_forward", "composite_rays_train_forward", M, "samples", 24 * M + (12 + 20) * N)
 line("composite_rays_train_backward", "composite_rays_train_backward", M, "samples", (24 + 16) * M + (12 + 4 + 12 + 4 + 12) * N)
 line("ffmlp_backward (both nets, averaged: activation + weight gradients in one pass, fixed-order reduction of the partials)", "ffmlp_backward", Mp, "rows",
-     (32 + 2.5 * 128 + 64 + 64) * Mp, flops_per_call=2 * (14336 + 22528) / 2 * Mp,
-     note="bytes: grad 32 + the stored activations (2 or 3 x 128 B per row) + inputs 64 + the input gradient 64; round 1's two-kernel form "
-          "moved 1472 B per row (activation gradients written and read back, activations read twice) and its table priced those")
+     (32 + 64 + 64) * Mp, flops_per_call=3 * (14336 + 22528) / 2 * Mp,
+     note="bytes: grad 32 + inputs 64 + the input gradient 64 (round 3: the activations are recomputed, 2 or 3 x 128 B per row were read "
+          "until then; flops include that forward pass); round 1's two-kernel form moved 1472 B per row")
 # (sh_encode_backward is not launched by a training step -- view directions carry no gradient there -- it is timed below, on
 #  the pose-gradient shape where it does run)
 line("grid_encode_backward f16 (table gradient, packed-half atomics)", "grid_encode_backward", Mp, "points", 588 * Mp,

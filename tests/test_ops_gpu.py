@@ -330,6 +330,33 @@ def test_grid_encode_strided_layouts_agree_with_the_level_major_operator(device,
                                                B * C + 1 if C > 1 else 0, C, st) != 0
 
 
+@pytest.mark.parametrize("layers,in_dim,B,act", [(2, 32, 4096, "relu"), (3, 32, 1040, "relu"), (4, 64, 272, "relu"), (3, 32, 528, "sigmoid")])
+def test_ffmlp_backward_recomputed_activations_equal_the_stored_ones(device, monkeypatch, layers, in_dim, B, act):
+    """The reference keeps every hidden layer's activations for the backward pass (forward_buffer, ffmlp.py:37-45).  For the 64-wide
+    networks the backward kernel can compute them again from the inputs with the forward kernel's own instruction sequence
+    (ngp_ffmlp_backward with forward_buffer == NULL): outputs, input gradients and weight gradients bit-identical to the stored form."""
+    import nerfsafetyvalidation_amd.ffmlp.ffmlp as F
+    from nerfsafetyvalidation_amd import _lib
+    assert _lib.lib().ngp_ffmlp_backward_recomputes(in_dim, 64, layers) == 1
+    assert _lib.lib().ngp_ffmlp_backward_recomputes(in_dim, 128, layers) == 0 and _lib.lib().ngp_ffmlp_backward_recomputes(16, 64, layers) == 0
+    torch.manual_seed(layers)
+    net = F.FFMLP(in_dim, 16, 64, layers, activation=act).to(device).train()
+    x0 = (torch.randn(B, in_dim, device=device) * 0.5).half()
+    g = torch.randn(B, 16, device=device).half()
+    res = []
+    for recompute in (True, False):
+        monkeypatch.setattr(F, "RECOMPUTE_ACTIVATIONS", recompute)
+        x = x0.clone().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = net(x)
+        y.backward(g)
+        res.append((y.detach().clone(), x.grad.clone(), net.weights.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert all(float(t.float().abs().max()) > 0 for t in res[0])
+
+
 @pytest.mark.parametrize("layers,B", [(2, 4096), (3, 1040), (4, 16)])
 def test_ffmlp_level_plane_inputs_equal_row_inputs(device, layers, B):
     """ngp_ffmlp_forward_planes / _backward_planes: the 64-wide FFMLP reading its 32 inputs from the hash-grid operator's level planes
