@@ -481,7 +481,7 @@ NGP_API int ngp_debug_set_stamps(unsigned long long* device_buf);
 /* Diagnostics: uint32[N] device buffer receiving, per ray, an FNV-1a hash over the bit patterns of (dt, deltas[1]) of every
  * sample the fused renderer marched, in order (NULL = off).  Lets a test prove the fused path's sample sequence equal to
  * march_rays' bit for bit.  ngp_debug_disable_march_queue(flags): bit 0 / bit 1 disable the coarse occupancy filter, bit 2 the
- * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bit 14 runs every multi-iteration launch as planned (no cut before the network from the march's own counts), bit 15 keeps the work items of k_render_iter at 64 list entries, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
+ * slow-ray grouping of the alive list, bit 3 the linear re-layout of the occupancy bits, bit 8 the launches that cover several reference iterations, bits 9-12 replace the safety factor those launches are sized with (value / 2; 0 = built-in), bit 13 ignores the frame-width hint, bit 14 runs every multi-iteration launch as planned (no cut before the network from the march's own counts), bit 15 keeps the work items of k_render_iter at 64 list entries, bit 16 replays a launch that failed its verification as one iteration instead of its verified prefix, bits 4-7 fold the hashed levels into size >> n entries (timing only, wrong images) (A/B experiments; bit 0 disables the one-step exit from empty 4x4x4 blocks, Dda::jump_block). */
 NGP_API int ngp_debug_set_sample_hash(uint32_t* device_buf);
 NGP_API int ngp_debug_disable_march_queue(int off);
 /* Diagnostics: the 32 hash-grid features of xyzs [M,3] (positions in [-bound, bound]) exactly as the fused kernels' gather forms them

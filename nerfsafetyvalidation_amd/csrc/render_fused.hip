@@ -2599,7 +2599,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
     const uint32_t first = g * 8;
     // ---- a launch that covered several reference iterations is verified first (every block reaches the same verdict) ----
     __shared__ uint32_t deaths[kSpecK], exhausted[kSpecK];
-    __shared__ uint32_t verdict_bad;
+    __shared__ uint32_t verdict_bad, verdict_keep;
     if (threadIdx.x < kSpecK) {
         uint32_t d = 0, x = 0;
         if (c.spec)
@@ -2615,20 +2615,24 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
     if (threadIdx.x == 0) {
         // K = c.n_step / q reference iterations of q = c.spec samples each: n_alive(i + j) = n_alive(i) - deaths before j.  Each must
         // have been run with n_step = clamp(N // n_alive, 1, 8) == q, and the loop would have stopped at the first empty list.
-        uint32_t bad = 0;
+        // `keep`: the iterations before the first violation.  They WERE the reference's (every ray was processed exactly as the
+        // reference processes it up to there, so their death counts are the true ones): a launch of just those verifies for certain.
+        uint32_t bad = 0, keep = 0;
         if (c.spec) {
             const uint32_t q = c.spec, K = c.n_step / q;
             uint32_t alive = c.n_alive;
+            keep = K;
             for (uint32_t j = 0; j < K; j++) {
                 if (alive == 0) break;                            // the reference stops here; the rest of the launch had no ray to touch
                 const uint32_t want_q = N / alive;
-                if (j > 0 && (want_q < 1 ? 1u : (want_q > 8 ? 8u : want_q)) != q) bad = 1;
+                if (j > 0 && (want_q < 1 ? 1u : (want_q > 8 ? 8u : want_q)) != q) { bad = 1; keep = j; break; }
                 alive -= deaths[j];
+                // the caller wants the reference's last-iteration tensors: that iteration has to run on its own (bit 1 of spec_allowed)
+                if ((spec_allowed & 2u) && alive == 0) { bad = 1; keep = j; break; }
             }
-            // the caller wants the reference's last-iteration tensors: that iteration has to run on its own (bit 1 of spec_allowed)
-            if ((spec_allowed & 2u) && alive == 0) bad = 1;
         }
         verdict_bad = bad;
+        verdict_keep = keep;
     }
     __syncthreads();
     if (verdict_bad) {
@@ -2644,11 +2648,19 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
         }
         if (g == n_blocks - 1 && threadIdx.x == 0) {
             Ctl n = c;
-            n.spec = 0;
-            const uint32_t ns = c.n_alive ? N / c.n_alive : 8;
-            n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
             n.rollbacks = c.rollbacks + 1;
-            n.backoff = 2;                                        // the next two iterations run one per launch
+            if (verdict_keep >= 2 && !(spec_allowed & 4u)) {
+                // the iterations before the violation again, as one launch: certain to verify (see `keep` above)
+                n.spec = c.spec;
+                n.n_step = verdict_keep * c.spec;
+                n.backoff = 0;
+                for (uint32_t i = 0; i < kDeathWords; i++) death_next[i] = 0;     // (the other parity's buffer: nobody reads it now)
+            } else {
+                n.spec = 0;
+                const uint32_t ns = c.n_alive ? N / c.n_alive : 8;
+                n.n_step = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
+                n.backoff = 2;                                    // the next two iterations run one per launch
+            }
             // (this launch's death counts are NOT cleared here: the other blocks of this kernel are still reading them for their
             //  verdict.  Launches alternate between two buffers; a buffer is cleared right before a multi-iteration launch uses it.)
             for (int i = 0; i < kStatShards; i++) stat_shards_rw[i] = 0ull;   // the discarded launch's sample counts
@@ -2923,6 +2935,7 @@ struct DebugState {
     bool tile_off() const { return (flags & 8192) != 0; }
     bool pre_verdict_off() const { return (flags & 16384) != 0; }
     bool narrow_items_off() const { return (flags & 32768) != 0; }
+    bool prefix_replay_off() const { return (flags & 65536) != 0; }
     uint32_t spec_safety_x2() const { return ((uint32_t)flags >> 9) & 15u; }   // 0: kSpecSafetyX2
     uint32_t shrink() const { return ((uint32_t)flags >> 4) & 15u; }
 };
@@ -3154,7 +3167,10 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     }
     // several reference iterations per launch (see Ctl): not with jitter
     // bit 0: launches may cover several reference iterations; bit 1: but never the last one (its tensors are wanted); bits 8..: diagnostics
-    const uint32_t spec_allowed = (!dbg.spec_off() && perturb == 0) ? (1u | (last_sigmas ? 2u : 0u) | (dbg.spec_safety_x2() << 8)) : 0u;
+    // bit 0: launches may cover several iterations; bit 1: the last iteration runs on its own; bit 2 (diagnostics): a failed launch is
+    // replayed as ONE iteration instead of its verified prefix; bits 8-11: safety factor override
+    const uint32_t spec_allowed = (!dbg.spec_off() && perturb == 0)
+                                      ? (1u | (last_sigmas ? 2u : 0u) | (dbg.prefix_replay_off() ? 4u : 0u) | (dbg.spec_safety_x2() << 8)) : 0u;
     // scheduling hint (ngp_render_ctx_set_frame_width): whole rows of 4x4-pixel tiles only; not with jitter (seeded with the list index)
     const uint32_t fw = ctx->frame_width;
     const uint32_t tile_w = (perturb == 0 && !dbg.tile_off() && fw >= 4 && fw % 4 == 0 && N % (4 * fw) == 0) ? fw : 0u;

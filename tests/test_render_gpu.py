@@ -317,7 +317,7 @@ def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
     outs = {}
     try:
         model.density_scale = 4.0e4
-        for flags in (0, 256):
+        for flags in (0, 65536, 256):      # verified prefix replayed as one launch (default) / one iteration replayed / one iteration per launch
             lib.ngp_debug_disable_march_queue(flags)
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 img = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False)["image"].float()
@@ -325,10 +325,12 @@ def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
     finally:
         model.density_scale = old_scale
         lib.ngp_debug_disable_march_queue(0)
-    assert outs[0][1]["replayed"] >= 1 and outs[256][1]["replayed"] == 0       # number of rolled-back launches
-    assert torch.equal(outs[0][0], outs[256][0])
-    for key in ("samples_marched", "samples_slots", "iterations"):
-        assert outs[0][1][key] == outs[256][1][key], key
+    assert outs[0][1]["replayed"] >= 1 and outs[65536][1]["replayed"] >= 1 and outs[256][1]["replayed"] == 0   # rolled-back launches
+    assert outs[0][1]["launches"] <= outs[65536][1]["launches"]
+    for flags in (0, 65536):
+        assert torch.equal(outs[flags][0], outs[256][0])
+        for key in ("samples_marched", "samples_slots", "iterations"):
+            assert outs[flags][1][key] == outs[256][1][key], (flags, key)
 
 
 def test_launch_cut_short_before_the_network_and_narrow_work_items(device):
