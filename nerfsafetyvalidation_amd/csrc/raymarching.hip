@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(kBlock) k_composite_train_bwd(const float* __r
     float* gs = grad_sigmas + offset;
     float* gr = grad_rgbs + (size_t)offset * 3;
     uint32_t step = 0;
-    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+    float T = 1.0f, r = 0, g = 0, b = 0;
     bool stop = false;
     while (step < num_steps && !stop) {
         const uint32_t nb = num_steps - step < 4u ? num_steps - step : 4u;
@@ -396,7 +396,6 @@ __global__ void __launch_bounds__(kBlock) k_composite_train_bwd(const float* __r
                 const float alpha = 1.0f - expf(-q.sg[k] * q.dl[2 * k]);
                 const float weight = alpha * T;
                 r = fmaf(weight, q.rg[3 * k], r); g = fmaf(weight, q.rg[3 * k + 1], g); b = fmaf(weight, q.rg[3 * k + 2], b);
-                ws += weight;
                 T *= 1.0f - alpha;
                 if (T < 1e-4f) {
                     stop = true;
