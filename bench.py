@@ -488,7 +488,7 @@ def main():
                 algo_bytes = units.value * TABLE_BYTES_PER_SAMPLE + ray_iters * RAY_BYTES_PER_RAY_ITER
                 achieved = algo_bytes / (ms.value * 1e-3) / 1e9
                 traffic, src = pmc_traffic_per_launch()
-                roof = {"kernel": "k_render_iter (fused march+hashgrid+MLPs+composite)", "bound": "hbm",
+                roof = {"kernel": "k_render_iter (hash grid + MLPs + compositing of one launch's samples; the occupancy march is k_march_ahead)", "bound": "hbm",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "traffic_unit": f"bytes per launch (profiles/{src}: FETCH_SIZE x2 + WRITE_SIZE)",
                         "achieved_bytes_per_launch": round(algo_bytes / n_launch.value), "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / n_launch.value, 4),
