@@ -28,20 +28,32 @@ class RunUniform(torch.autograd.Function):
     (ngp_render_uniform_backward) -- differentiable in the rays, the map frozen: the pose gradients of the state estimator."""
 
     @staticmethod
-    def forward(ctx, fm, rays_o, rays_d, nears, fars, num_steps, dump_begin, frame_width=0):
+    def forward(ctx, fm, rays_o, rays_d, nears, fars, num_steps, dump_begin, frame_width=0, bg=None):
+        """bg: None, or one background colour for every ray (float or 3 floats): `image + (1 - weights_sum)[:, None] * bg`
+        (renderer.py:204) is then part of this node -- the same three torch operations, without their four autograd nodes each way
+        (the state estimator runs this step a hundred times per simulator step, and at 1024 rays the step is host time)."""
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         ws, depth, image, agg, sigmas, rgbs = fm.render_uniform(rays_o, rays_d, nears, fars, num_steps, dump_begin, frame_width)
         ctx.fm, ctx.num_steps = fm, num_steps
+        ctx.bg = None
+        if bg is not None:
+            ctx.bg = torch.tensor(bg, dtype=torch.float32, device=image.device) if isinstance(bg, (tuple, list)) else float(bg)
+            image = image + (1 - ws).unsqueeze(-1) * ctx.bg
         ctx.save_for_backward(rays_o, rays_d, nears, fars)
         ctx.mark_non_differentiable(sigmas, rgbs)
+        ctx.set_materialize_grads(False)
         return ws, depth, image, agg, sigmas, rgbs
 
     @staticmethod
     def backward(ctx, g_ws, g_depth, g_image, g_agg, _g_sigmas, _g_rgbs):
         rays_o, rays_d, nears, fars = ctx.saved_tensors
+        if g_image is not None and ctx.bg is not None:
+            # d image / d weights_sum = -bg per channel: what autograd's Mul / Rsub nodes hand back, accumulated onto the direct gradient
+            via = -((g_image * ctx.bg).sum(-1))
+            g_ws = via if g_ws is None else g_ws + via
         zeros = g_image if g_image is not None else torch.zeros(rays_o.shape[0], 3, device=rays_o.device)
         go, gd = ctx.fm.render_uniform_backward(rays_o, rays_d, nears, fars, ctx.num_steps, zeros, g_depth, g_ws, g_agg)
-        return None, go, gd, None, None, None, None, None
+        return None, go, gd, None, None, None, None, None, None
 
 
 def _versions(tensors):

@@ -386,10 +386,18 @@ class NeRFRenderer(nn.Module):
             if upsample_steps > 0:      # importance resampling (evaluation mode, no gradients: the caller checked)
                 ws, dep, img, ag, sigmas, rgbs = fm.render_upsample(o, d, nears, fars, int(num_steps), int(upsample_steps), last_begin,
                                                                     int(kwargs.get("frame_width", 0) or 0))
+                img = img + (1 - ws).unsqueeze(-1) * (1 if bg_color is None else bg_color)
             else:
-                ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin, int(kwargs.get("frame_width", 0) or 0))
-            img = img + (1 - ws).unsqueeze(-1) * (1 if bg_color is None else bg_color)
+                bg = 1 if bg_color is None else bg_color
+                const = isinstance(bg, (int, float)) or (isinstance(bg, (tuple, list)) and len(bg) == 3 and all(isinstance(v, (int, float)) for v in bg))
+                ws, dep, img, ag, sigmas, rgbs = RunUniform.apply(fm, o, d, nears, fars, int(num_steps), last_begin, int(kwargs.get("frame_width", 0) or 0),
+                                                                  bg if const else None)
+                if not const:
+                    img = img + (1 - ws).unsqueeze(-1) * bg
             depth.append(dep), image.append(img), agg.append(ag)
+        if B == 1:       # (views instead of one-element stacks: three copies and their autograd nodes less per estimator step)
+            return {"depth": depth[0].unsqueeze(0), "image": image[0].unsqueeze(0), "rgbs": rgbs, "sigmas": sigmas,
+                    "aggregated_density": agg[0].unsqueeze(0)}
         return {"depth": torch.stack(depth, 0), "image": torch.stack(image, 0), "rgbs": rgbs, "sigmas": sigmas,
                 "aggregated_density": torch.stack(agg, 0)}
 

@@ -14,8 +14,9 @@ H = W = 800
 sc = StonehengeScene(H=H, W=W, bound=2)
 # (the FFMLP backbone has no backward in eval mode -- ffmlp.py:107 passes inference = not self.training, as the reference does --
 #  so the estimator runs on nerf/network.py, with and without autocast)
-for backbone, autocast, fused in (("linear", True, True), ("ff", True, True), ("linear", True, False), ("linear", False, False)):
-    model = sc.build_model(dev, backbone=backbone, cuda_ray=False)
+# (first line: what validate.py runs -- nn.Linear backbone, fp32 table, no autocast)
+for backbone, autocast, fused in (("linear", False, True), ("linear", True, True), ("ff", True, True), ("linear", True, False), ("linear", False, False)):
+    model = sc.build_model(dev, backbone=backbone, cuda_ray=False, fp16_table=autocast)
     model.fused = fused
     for p in model.parameters():
         p.requires_grad_(False)          # the map is frozen while the pose is estimated
