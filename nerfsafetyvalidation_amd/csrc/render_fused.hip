@@ -2227,7 +2227,9 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
     uint32_t emitted = 0;
     float2* out = ra.march_samples + ((size_t)(entry >> 6) * n_step) * 64 + (entry & 63u);
     float x, y, z, dt;
+    uint32_t probes = 0;                 // diagnostics (ra.stamps): probes of this lane
     while (t_march < far && emitted < n_step) {
+        probes++;
         if (LIN ? dda.probe_lin(t_march, x, y, z, dt, coarse) : dda.probe(t_march, x, y, z, dt, coarse)) {
             out[(size_t)emitted * 64] = make_float2(t_march, dt);
             t_march += dt;
@@ -2244,6 +2246,21 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
     // Rays whose next march begins inside an empty 4x4x4 block are about to skip through empty space (tens of DDA probes) while the
     // others take one probe per sample: k_render_iter groups them into their own chunks (a scheduling decision only).  The flag is
     // meaningful for rays that complete all n_step samples -- the survivors -- whose rays_t then is geo_tc.
+    if (ra.stamps) {   // diagnostics only: [4] sum over waves of the slowest lane's probes, [5] all probes, [6] waves, [7] the slowest lane of all
+        uint32_t mx = probes, sm = probes;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mx, off, 64), p2 = (uint32_t)__shfl_xor((int)sm, off, 64);
+            mx = mx > o ? mx : o;
+            sm += p2;
+        }
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) {
+            atomicAdd(ra.stamps + 4, (unsigned long long)mx);
+            atomicAdd(ra.stamps + 5, (unsigned long long)sm);
+            atomicAdd(ra.stamps + 6, 1ull);
+            atomicMax(ra.stamps + 7, (unsigned long long)mx);
+        }
+    }
     if (spec && ra.pre_verdict) {     // the iteration of this launch in which the ray's march runs out (truncate_launch); wave-aggregated, sharded counters
         const uint32_t K = n_step / spec, jd = emitted < n_step ? emitted / spec : 0xFFFFFFFFu;
         const unsigned long long act = __ballot(true);
