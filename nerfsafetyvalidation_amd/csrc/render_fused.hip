@@ -2599,7 +2599,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
                                                          const float4* __restrict__ backup, float* __restrict__ rays_t, float* __restrict__ weights_sum,
                                                          float* __restrict__ depth, float* __restrict__ image, uint32_t* __restrict__ sample_hash,
                                                          unsigned long long* stat_shards_rw, uint32_t* __restrict__ death_next, uint32_t wave_slots,
-                                                         uint32_t cap_mid_max) {
+                                                         uint32_t cap_mid_max, uint32_t cap_hi) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
     Ctl c = *cur;
@@ -2781,7 +2781,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             // at most 8 samples per ray and launch while n_step is small; in the n_step >= 5 regimes (few rays, every launch
             // latency-bound) up to kSpecMaxSamples.  With n_step = 8 the guess cannot fail: N // n_alive only grows as rays die.
             const uint32_t cap_mid = 8u * q < cap_mid_max ? 8u * q : cap_mid_max;      // (n_alive <= N / q: at most 8 N samples per launch)
-            const uint32_t cap_samples = q == 1 ? 8u : (q <= 4 ? cap_mid : kSpecMaxSamples);
+            const uint32_t cap_samples = q == 1 ? 8u : (q <= 4 ? cap_mid : cap_hi);
             const uint32_t capK = cap_samples / q < kSpecK ? cap_samples / q : kSpecK;
             K = (q == 8 && !own_last) ? capK : (K < capK ? K : capK);
             K = K < room ? K : room;
@@ -3276,6 +3276,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
 
     static const uint32_t cap_mid_env = getenv("NGP_SPEC_CAP_MID") ? (uint32_t)atoi(getenv("NGP_SPEC_CAP_MID")) : 8u;
     const uint32_t cap_mid_max = cap_mid_env < 8u ? 8u : (cap_mid_env > kSpecMaxSamples ? kSpecMaxSamples : cap_mid_env);
+    static const uint32_t cap_hi_env = getenv("NGP_SPEC_CAP_HI") ? (uint32_t)atoi(getenv("NGP_SPEC_CAP_HI")) : kSpecMaxSamples;
+    const uint32_t cap_hi = cap_hi_env < 8u ? 8u : (cap_hi_env > kSpecMaxSamples ? kSpecMaxSamples : cap_hi_env);
     uint32_t ub = N;          // host-side upper bound of n_alive
     uint32_t launched = 0;    // iterations enqueued
     uint32_t known = 0;       // iterations whose resulting status the host has read
@@ -3305,7 +3307,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
                                                            ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1,
                                                            ctx->death_shards + (size_t)cur * kDeathWords, spec_allowed, ctx->alive[cur],
                                                            ctx->backup, ctx->rays_t, weights_sum, depth, image, dbg.sample_hash, ctx->stat_shards,
-                                                           ctx->death_shards + (size_t)(cur ^ 1) * kDeathWords, ra.wave_slots, cap_mid_max);
+                                                           ctx->death_shards + (size_t)(cur ^ 1) * kDeathWords, ra.wave_slots, cap_mid_max, cap_hi);
         launched++;
         launches += 3;
         // consume every status that has already landed; block only when too far ahead
