@@ -272,10 +272,36 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
         } else {
             const uint32_t hashmap_size = lv.offset[level + 1] - lv.offset[level];
             const uint32_t* tab = tab32 + lv.offset[level];
+            // The two x-neighbours of a corner pair are adjacent entries wherever the index is linear in x: always on a dense level
+            // (e, e + 1), and on a hashed power-of-two level when x is even (the prime of dimension 0 is 1: x ^ h and (x + 1) ^ h = e ^ 1
+            // share an aligned 8-byte word).  One 8-byte load then serves both: the L1 processes one tag look-up per distinct line and
+            // instruction, which is what bounds this kernel on ray-ordered points.  Same entries, same values.
+            const uint32_t mode = lv.mode[level];
+            const bool hashed = lv.hashed[level] != 0;
+            if (!hashed && mode == 0) {
 #pragma unroll
-            for (int idx = 0; idx < 8; idx++) {
-                const uint32_t pl[D] = {pg[0] + (idx & 1), pg[1] + ((idx >> 1) & 1), pg[2] + ((idx >> 2) & 1)};
-                raw[i][idx] = tab[grid_entry_lv<D>(lv, level, hashmap_size, pl)];
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t pl[D] = {pg[0], pg[1] + (j & 1), pg[2] + ((j >> 1) & 1)};
+                    const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
+                    uint2 v;
+                    __builtin_memcpy(&v, tab + e, 8);          // (4-byte aligned: an unaligned dwordx2 load)
+                    raw[i][2 * j] = v.x; raw[i][2 * j + 1] = v.y;
+                }
+            } else if (hashed && mode == 1 && (pg[0] & 1u) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t pl[D] = {pg[0], pg[1] + (j & 1), pg[2] + ((j >> 1) & 1)};
+                    const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
+                    const uint2 v = *reinterpret_cast<const uint2*>(tab + (e & ~1u));
+                    raw[i][2 * j] = (e & 1u) ? v.y : v.x;
+                    raw[i][2 * j + 1] = (e & 1u) ? v.x : v.y;
+                }
+            } else {
+#pragma unroll
+                for (int idx = 0; idx < 8; idx++) {
+                    const uint32_t pl[D] = {pg[0] + (idx & 1), pg[1] + ((idx >> 1) & 1), pg[2] + ((idx >> 2) & 1)};
+                    raw[i][idx] = tab[grid_entry_lv<D>(lv, level, hashmap_size, pl)];
+                }
             }
         }
     }
