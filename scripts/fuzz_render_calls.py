@@ -20,7 +20,7 @@ bad = 0
 for i in range(n_calls):
     b = int(rng.choice([1, 2, 4]))
     sc, model = scenes[b], models[b]
-    n = int(rng.choice([1, 7, 64, 77, 199, 1000, 2111, 3000, 4096]))
+    n = int(rng.choice([1, 7, 16, 17, 64, 77, 199, 1000, 2111, 3000, 4096]))
     perturb = bool(rng.random() < 0.25)
     max_steps = int(rng.choice([1024, 1024, 512, 100, 16, 3]))
     hint = bool(rng.random() < 0.5)
@@ -36,7 +36,7 @@ for i in range(n_calls):
         a = model.render(ro, rd, **kw); sa = dict(model.last_render_stats)
         a2 = model.render(ro, rd, **kw)
         # the same call with one of the renderer's shortcuts switched off (or without the last-iteration tensors): identical bits
-        flags = int(rng.choice([1, 2, 4, 6, 8, 10, 256, 8192, 0]))
+        flags = int(rng.choice([1, 2, 4, 6, 8, 10, 256, 8192, 16384, 32768, 65536, 16384 | 32768 | 65536, 0]))   # (bits 14-16: round 3's launch cut, narrow items, prefix replay)
         lib.ngp_debug_disable_march_queue(flags)
         model.return_last_tensors = bool(rng.random() < 0.7)
         try:
