@@ -659,16 +659,17 @@ __device__ __forceinline__ void fused_gather32(const NetArgs& na, const LevelTab
 // gridencoder.cu:139-175 in fp32: results[ch] += w * grid[index + ch] over the corners in index order (one fma each under nvcc's
 // -fmad; the operator and the oracle write it as fmaf) -- bit-identical to grid_encode's fp32 features
 __device__ __forceinline__ void corners_to_feature32(const float (&fr)[3], const float2 (&raw)[8], bool oob, float& f0, float& f1) {
-    float a0 = 0.0f, a1 = 0.0f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc = {0.0f, 0.0f};                           // both features of a corner in one v_pk_fma_f32 (an IEEE fma per component)
 #pragma unroll
     for (int idx = 0; idx < 8; idx++) {
         const float wx = (idx & 1) ? fr[0] : 1 - fr[0];
         const float wy = (idx & 2) ? fr[1] : 1 - fr[1];
         const float wz = (idx & 4) ? fr[2] : 1 - fr[2];
         const float w = (wx * wy) * wz;
-        a0 = fmaf(w, raw[idx].x, a0);
-        a1 = fmaf(w, raw[idx].y, a1);
+        acc = __builtin_elementwise_fma((f32x2){w, w}, (f32x2){raw[idx].x, raw[idx].y}, acc);
     }
+    const float a0 = acc[0], a1 = acc[1];
     f0 = oob ? 0.0f : a0;
     f1 = oob ? 0.0f : a1;
 }
