@@ -79,6 +79,37 @@ __device__ __forceinline__ uint32_t grid_entry_lv(const GridLevels& lv, uint32_t
     return index;
 }
 
+// The entry indices of all 2^D corners of a cell from shared terms: per dimension ONE product for the low corner and an addition for
+// the high one -- (p + 1) * m = p * m + m in wrap-around arithmetic -- where calling grid_entry_lv per corner spends D integer
+// multiplies on each (v_mul_lo_u32 is a quarter-rate instruction on gfx950: 16 of them per point and level were a quarter of the
+// forward kernel's instruction time).  Same indices, bit for bit.
+template <int D>
+struct CornerIndex {
+    uint32_t t[D][2];
+    uint32_t size, mode;
+    bool hashed;
+    __device__ __forceinline__ CornerIndex(const GridLevels& lv, uint32_t level, uint32_t hashmap_size, const uint32_t (&pg)[D]) {
+        constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+        hashed = lv.hashed[level] != 0;
+        mode = lv.mode[level];
+        size = hashmap_size;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const uint32_t m = hashed ? primes[d] : (d == 0 ? 1u : (d == 1 ? lv.mul1[level] : lv.mul2[level]));
+            t[d][0] = pg[d] * m;
+            t[d][1] = t[d][0] + m;
+        }
+    }
+    __device__ __forceinline__ uint32_t at(int idx) const {
+        uint32_t e = t[0][idx & 1];
+#pragma unroll
+        for (int d = 1; d < D; d++) e = hashed ? (e ^ t[d][(idx >> d) & 1]) : (e + t[d][(idx >> d) & 1]);
+        if (mode == 1) e &= size - 1u;
+        else if (mode == 2) e %= size;
+        return e;
+    }
+};
+
 // acc += w * g with the reference's scalar_t semantics (c10::Half arithmetic, gridencoder.cu:169-172):
 // f32: one fma; f16: product rounded to half, then a half add.
 __device__ __forceinline__ void acc_mul(float& acc, float w, float g) { acc = fmaf(w, g, acc); }
@@ -150,14 +181,9 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
 
     // gather the 2^D corners (all loads issued before any use)
     V corner[1 << D];
+    const CornerIndex<D> ci(lv, level, hashmap_size, pg);
 #pragma unroll
-    for (int idx = 0; idx < (1 << D); idx++) {
-        uint32_t pl[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
-        const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
-        corner[idx] = *reinterpret_cast<const V*>(tab + (size_t)e * C);
-    }
+    for (int idx = 0; idx < (1 << D); idx++) corner[idx] = *reinterpret_cast<const V*>(tab + (size_t)ci.at(idx) * C);
 
     V res;
 #pragma unroll
@@ -278,11 +304,11 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
             // instruction, which is what bounds this kernel on ray-ordered points.  Same entries, same values.
             const uint32_t mode = lv.mode[level];
             const bool hashed = lv.hashed[level] != 0;
+            const CornerIndex<D> ci(lv, level, hashmap_size, pg);
             if (!hashed && mode == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t pl[D] = {pg[0], pg[1] + (j & 1), pg[2] + ((j >> 1) & 1)};
-                    const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
+                    const uint32_t e = ci.at(2 * j);
                     uint2 v;
                     __builtin_memcpy(&v, tab + e, 8);          // (4-byte aligned: an unaligned dwordx2 load)
                     raw[i][2 * j] = v.x; raw[i][2 * j + 1] = v.y;
@@ -290,18 +316,14 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
             } else if (hashed && mode == 1 && (pg[0] & 1u) == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t pl[D] = {pg[0], pg[1] + (j & 1), pg[2] + ((j >> 1) & 1)};
-                    const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
+                    const uint32_t e = ci.at(2 * j);
                     const uint2 v = *reinterpret_cast<const uint2*>(tab + (e & ~1u));
                     raw[i][2 * j] = (e & 1u) ? v.y : v.x;
                     raw[i][2 * j + 1] = (e & 1u) ? v.x : v.y;
                 }
             } else {
 #pragma unroll
-                for (int idx = 0; idx < 8; idx++) {
-                    const uint32_t pl[D] = {pg[0] + (idx & 1), pg[1] + ((idx >> 1) & 1), pg[2] + ((idx >> 2) & 1)};
-                    raw[i][idx] = tab[grid_entry_lv<D>(lv, level, hashmap_size, pl)];
-                }
+                for (int idx = 0; idx < 8; idx++) raw[i][idx] = tab[ci.at(idx)];
             }
         }
     }
@@ -449,16 +471,13 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_backward(const T* __restric
         for (int c = 0; c < C; c++) g[c] = 0.0f;
     }
     valid = valid && nonzero;          // a zero gradient adds nothing: no atomics (see k_grid_bwd_bin)
+    const CornerIndex<D> ci(lv, level, hashmap_size, pg);
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float w = 1;
-        uint32_t pl[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
-            pl[d] = pg[d] + ((idx >> d) & 1);
-        }
-        const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
+        for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+        const uint32_t e = ci.at(idx);
         float v[C];
 #pragma unroll
         for (int c = 0; c < C; c++) v[c] = w * g[c];
@@ -559,12 +578,10 @@ __global__ void __launch_bounds__(kSmallThreads) k_grid_backward_small(const T* 
             for (int c = 0; c < C; c++) v[idx * C + c] = w * g[c];
         }
         if (merge_cell_rows<D>(valid, pg, v)) {
+            const CornerIndex<D> ci(lv, level, hashmap_size, pg);
 #pragma unroll
             for (int idx = 0; idx < (1 << D); idx++) {
-                uint32_t pl[D];
-#pragma unroll
-                for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
-                const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
+                const uint32_t e = ci.at(idx);
 #pragma unroll
                 for (int c = 0; c < C; c++) {
                     if constexpr (sizeof(T) == 2) {
@@ -715,12 +732,10 @@ __global__ void __launch_bounds__(NT) k_grid_bwd_bin(const _Float16* __restrict_
 #pragma unroll
     for (int idx = 0; idx < NC; idx++) key[idx] = kMergeEmpty;
     if (tail) {
+        const CornerIndex<D> ci(lv, level, hashmap_size, pg);
 #pragma unroll
         for (int idx = 0; idx < NC; idx++) {
-            uint32_t pl[D];
-#pragma unroll
-            for (int d = 0; d < D; d++) pl[d] = pg[d] + ((idx >> d) & 1);
-            const uint32_t e = grid_entry_lv<D>(lv, level, hashmap_size, pl);
+            const uint32_t e = ci.at(idx);
             const uint32_t bin = bin_of(e, hashed);
             const uint32_t k19 = slot_of(e, hashed) | (bin << kBinLog);
             const uint32_t hv = to_half2(v[idx * 2], v[idx * 2 + 1]);

@@ -57,8 +57,9 @@ grad_nonzero = None
 M = None
 PROF = os.environ.get("NGP_BENCH_NO_PROF") is None   # (the per-operator events serialise nothing, but cost a few host calls per launch)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-for it in range(1 + REPS):
-    if it == 1:
+WARM = 2          # (two untimed steps: the first process on a fresh box spends its first step growing the allocator's pools)
+for it in range(WARM + REPS):
+    if it == WARM:
         torch.cuda.synchronize(); lib.ngp_prof_reset(); lib.ngp_prof_enable(1 if PROF else 0)
         ev[0].record()
     rays = get_rays(poses[it:it + 1], sc.intrinsics, H, W)
@@ -69,7 +70,7 @@ for it in range(1 + REPS):
     # fp16 training runs under torch.cuda.amp.GradScaler (nerf/utils.py:350, init_scale 2^16): without the scale the gradients of a
     # 640 k-ray mean underflow to zero in fp16 and the backward kernels -- which skip zero gradients -- would have nothing to do
     (loss * LOSS_SCALE).backward()
-    if it == REPS:
+    if it == WARM + REPS - 1:
         g = model.encoder.embeddings.grad
         grad_nonzero = float((g != 0).any(dim=-1).float().mean())
     for p_ in model.parameters():
