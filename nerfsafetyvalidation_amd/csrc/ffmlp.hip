@@ -44,11 +44,17 @@ __device__ __forceinline__ float act_apply(uint32_t act, float v) {  // utils.h:
 }
 
 __device__ __forceinline__ half4 act_pack(uint32_t act, const f32x4& acc) {
+    if (act == 0) {
+        // ReLU on the fp16-rounded accumulator: two v_cvt_pk_f16_f32 and two v_pk_max_f16 instead of a conversion, a compare and a
+        // select per element.  max(a, +0) is `a > 0 ? a : 0` for every input: -0 gives +0 and a NaN gives 0 either way.
+        half4 h = __builtin_convertvector(acc, half4);
+        return __builtin_elementwise_max(h, (half4){0, 0, 0, 0});
+    }
     half4 h;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const _Float16 a = (_Float16)acc[r];  // accumulator -> fp16 (the reference's fragment dtype)
-        h[r] = (act == 0) ? (a > (_Float16)0 ? a : (_Float16)0) : (_Float16)act_apply(act, (float)a);
+        h[r] = (_Float16)act_apply(act, (float)a);
     }
     return h;
 }
@@ -64,10 +70,7 @@ __device__ __forceinline__ half4 act_hidden(uint32_t act, const f32x4& acc) {
 }
 __device__ __forceinline__ half4 act_output(uint32_t act, const f32x4& acc) {
     if (act > 5u) {   // none
-        half4 h;
-#pragma unroll
-        for (int r = 0; r < 4; r++) h[r] = (_Float16)acc[r];
-        return h;
+        return __builtin_convertvector(acc, half4);
     }
     return act_pack_call(act, acc);
 }
@@ -404,9 +407,10 @@ __device__ __forceinline__ _Float16 act_transfer(uint32_t act, _Float16 g, _Floa
 }
 
 __device__ __forceinline__ half4 transfer_pack(uint32_t act, const f32x4& acc, half4 f) {
+    const half4 g = __builtin_convertvector(acc, half4);      // (two packed conversions)
     half4 h;
 #pragma unroll
-    for (int r = 0; r < 4; r++) h[r] = act_transfer(act, (_Float16)acc[r], f[r]);
+    for (int r = 0; r < 4; r++) h[r] = act_transfer(act, g[r], f[r]);
     return h;
 }
 
@@ -543,9 +547,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_chain(const _Float16* __restr
                 }
 #pragma unroll
                 for (int t = 0; t < TPW; t++) {
-                    half4 h;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) h[r] = (_Float16)acc[t][r];
+                    const half4 h = __builtin_convertvector(acc[t], half4);
                     if (valid[t]) st_half4(grad_inputs + row[t] * in_dim + ib * 16 + g * 4, h);
                 }
             }
@@ -770,9 +772,7 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
                 }
 #pragma unroll
                 for (int t = 0; t < (int)TPW; t++) {
-                    half4 h;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) h[r] = (_Float16)acc[t][r];
+                    const half4 h = __builtin_convertvector(acc[t], half4);
                     if (valid[t]) st_in4<PLANES>(grad_inputs, row[t], ib * 16 + g * 4, in_dim, B, h);
                 }
             }
