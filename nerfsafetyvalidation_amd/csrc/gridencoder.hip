@@ -226,6 +226,19 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward(const float* __rest
 }
 
 // ---- the common shape (3-D, two fp16 features) with several levels per lane ---------------------------------------------------------
+// w * (one half of a packed pair) as an fp32 product (v_fma_mix_f32 with a -0 addend: the product rounded to fp32, exactly mul_round_f16's
+// first rounding) -- the second rounding is the conversion to half that follows
+__device__ __forceinline__ float mix_mul_lo(float w, uint32_t packed) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(-0.0f));
+    return r;
+}
+__device__ __forceinline__ float mix_mul_hi(float w, uint32_t packed) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed), "v"(-0.0f));
+    return r;
+}
+
 // One lane owns a point for a small set of levels: the point is read once for the set, 16 (32) gathers are in flight per lane, and a
 // wave writes 64 consecutive points of a level plane (256 contiguous bytes).
 // With per-cell corner records (ngp_build_cell_tables; `cells` != NULL) the first `cell_levels` levels read one 32-byte record
@@ -334,16 +347,20 @@ __global__ void __launch_bounds__(kGridBlock) k_grid_forward_g4(const float* __r
         V corner[8];
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) corner[idx] = __builtin_bit_cast(V, raw[i][idx]);
-        V res;
-        res.v[0] = (_Float16)0; res.v[1] = (_Float16)0;
+        // acc_mul's arithmetic (c10::Half: product rounded to fp32, then to half, then a half addition) on both features of a corner at
+        // once: two v_fma_mix_f32, one v_cvt_pk_f16_f32, one v_pk_add_f16 -- as the fused kernels' reference-rounding gather does
+        typedef _Float16 half2g __attribute__((ext_vector_type(2)));
+        half2g hs = {(_Float16)0, (_Float16)0};
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
             float w = 1;
 #pragma unroll
             for (int d = 0; d < D; d++) w *= ((idx >> d) & 1) ? fr[i][d] : 1 - fr[i][d];
-            acc_mul(res.v[0], w, corner[idx].v[0]);
-            acc_mul(res.v[1], w, corner[idx].v[1]);
+            const half2g pr = {(_Float16)mix_mul_lo(w, raw[i][idx]), (_Float16)mix_mul_hi(w, raw[i][idx])};
+            hs = hs + pr;
         }
+        V res;
+        res.v[0] = hs[0]; res.v[1] = hs[1];
         *reinterpret_cast<V*>(outputs + io.at(level, b)) = res;
         if (GRAD) {     // :177-222
             const float scale = lv.scale[level];
