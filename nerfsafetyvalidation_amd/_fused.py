@@ -100,7 +100,8 @@ class FusedModel:
         else:
             # fp16 copy of the table and, later, its per-cell records: shared with the grid_encode operator (one entry per parameter version)
             self._tables = derived_tables(enc.embeddings)
-            emb16 = self._tables.emb16
+            emb16 = self._tables.table_for_current_stream()     # (this stream waits for the copy if another thread's stream made it;
+                                                                #  the synchronize below then covers every stream that renders later)
         self.device = emb16.device
         self.emb16, self.sigma_blob, self.color_blob = emb16, sigma_blob, color_blob      # (emb16: the table in the model's precision)
         self.sigma_mm, self.color_mm = sigma_mm, color_mm

@@ -167,8 +167,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
-    """torch's CURRENT stream (the reference launches on the legacy default stream)"""
+    """torch's CURRENT stream of the current device (the reference launches on the legacy default stream).  Asked a dozen
+    times per training step: the raw handle comes straight from torch's C layer when it offers it (a tenth of the cost of building a
+    torch.cuda.Stream object each time)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
