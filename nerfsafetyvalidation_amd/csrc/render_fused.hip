@@ -2586,8 +2586,23 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd) k_render_iter(NetArgs
 // straight into its pinned, coherent status ring as ONE 64-bit word (sequence number << 32 | done << 31 | n_alive), written
 // with a relaxed system-scope store: no copy, no event, and no release fence (a fence writes the XCD's L2 back, ~10 us at the
 // end of this short kernel).  Everything else the host reads from the device state after the loop.
-__device__ __forceinline__ void publish_status(unsigned long long* host_slot, const Ctl& n, uint32_t seq) {
+// A state that ends the loop also leaves the counters the host reports (ngp_render_stats) in four more pinned words, each carrying a
+// tag in its upper 16 bits that names the render CALL (bit 15 set + a per-context call counter: the run-ahead no-op launches of the
+// previous call may still be writing their own, older tag when this call starts; the host takes a word once it carries this call's
+// tag -- every launch of a call that publishes a finished state writes the same values, so there is nothing to tear) -- the host then needs neither a stream
+// synchronize nor a copy of the device state at the end of a frame, and the caller can enqueue the next frame's work at once.
+__device__ __forceinline__ void publish_status(unsigned long long* host_slot, const Ctl& n, uint32_t seq, unsigned long long* fin = nullptr,
+                                               uint32_t call_tag = 0) {
     if (!host_slot) return;
+    if (n.done && fin) {
+        const unsigned long long tag = (unsigned long long)(0x8000u | (call_tag & 0x7FFFu)) << 48;
+        __hip_atomic_store(fin + 0, tag | (n.samples_marched & 0xFFFFFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin + 1, tag | (n.samples_slots & 0xFFFFFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin + 2, tag | ((unsigned long long)(n.iters & 0xFFFFFFu) << 24) | (n.rollbacks & 0xFFFFFFu), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin + 3, tag | ((unsigned long long)n.last_n_alive << 8) | (n.last_n_step & 0xFFu), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const unsigned long long w = ((unsigned long long)seq << 32) | ((unsigned long long)(n.done ? 1u : 0u) << 31) | (n.n_alive & 0x7FFFFFFFu);
     __hip_atomic_store(host_slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -2600,14 +2615,14 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
                                                          const float4* __restrict__ backup, float* __restrict__ rays_t, float* __restrict__ weights_sum,
                                                          float* __restrict__ depth, float* __restrict__ image, uint32_t* __restrict__ sample_hash,
                                                          unsigned long long* stat_shards_rw, uint32_t* __restrict__ death_next, uint32_t wave_slots,
-                                                         uint32_t cap_mid_max, uint32_t cap_hi) {
+                                                         uint32_t cap_mid_max, uint32_t cap_hi, unsigned long long* __restrict__ fin_host, uint32_t call_tag) {
     __shared__ uint32_t red[3][4];
     __shared__ uint32_t off_f[9], off_s[9];
     Ctl c = *cur;
     if (c.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             *nxt = c;
-            publish_status(host_slot, c, seq);
+            publish_status(host_slot, c, seq, fin_host, call_tag);
         }
         return;
     }
@@ -2686,7 +2701,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             for (int i = 0; i < kStatShards; i++) stat_shards_rw[i] = 0ull;   // the discarded launch's sample counts
             *nxt = n;
             for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
-            publish_status(host_slot, n, seq);
+            publish_status(host_slot, n, seq, fin_host, call_tag);
         }
         return;
     }
@@ -2792,7 +2807,7 @@ __global__ void __launch_bounds__(256) k_render_compact(const Ctl* __restrict__ 
             for (uint32_t i = 0; i < kDeathWords; i++) death_next[i] = 0;
         *nxt = n;
         for (int i = 0; i < 8; i++) nxt_heads->head[i][0] = 0;
-        publish_status(host_slot, n, seq);
+        publish_status(host_slot, n, seq, fin_host, call_tag);
     }
 }
 
@@ -2931,6 +2946,9 @@ struct ngp_render_ctx {
     _Float16* packed = nullptr;  // device
     unsigned long long* status = nullptr;       // pinned, coherent [kRing] status words: written by k_render_compact, polled by the host
     unsigned long long* status_dev = nullptr;   // the same ring as the device addresses it
+    unsigned long long* fin = nullptr;          // pinned, coherent [4]: the counters of a finished loop (publish_status)
+    unsigned long long* fin_dev = nullptr;
+    uint32_t calls = 0;                         // render calls made with this context (the tag of the words in `fin`)
     uint32_t seq_base = 0;       // sequence numbers already used by earlier render calls (slots are matched by number)
     hipEvent_t ev[kRing];
     int num_cu = 256;
@@ -3128,6 +3146,11 @@ int ngp_render_ctx_create(uint32_t max_rays, ngp_render_ctx** out) {
         memset(c->status, 0, kRing * sizeof(unsigned long long));
         ok &= hipHostGetDevicePointer((void**)&c->status_dev, c->status, 0) == hipSuccess;
     }
+    ok &= hipHostMalloc(&c->fin, 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) {
+        memset(c->fin, 0, 4 * sizeof(unsigned long long));
+        ok &= hipHostGetDevicePointer((void**)&c->fin_dev, c->fin, 0) == hipSuccess;
+    }
     for (int i = 0; i < kRing; i++) ok &= hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -3149,9 +3172,11 @@ int ngp_render_ctx_set_frame_width(ngp_render_ctx* ctx, uint32_t width) {
 
 int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     if (!c) return NGP_OK;
+    (void)hipDeviceSynchronize();      // a render call no longer ends with a synchronize: its run-ahead launches may still use the scratch
     (void)hipFree(c->alive[0]); (void)hipFree(c->alive[1]); (void)hipFree(c->staging); (void)hipFree(c->chunk_count);
     (void)hipFree(c->rays_t); (void)hipFree(c->coarse); (void)hipFree(c->grid_lin); (void)hipFree(c->death_shards); (void)hipFree(c->backup); (void)hipFree(c->march_samples); (void)hipFree(c->march_counts); (void)hipFree(c->dump_rec); (void)hipFree(c->dump_iter); (void)hipFree(c->ctl); (void)hipFree(c->stat_shards); (void)hipFree(c->heads); (void)hipFree(c->packed);
     if (c->status) (void)hipHostFree(c->status);
+    if (c->fin) (void)hipHostFree(c->fin);
     for (int i = 0; i < kRing; i++) (void)hipEventDestroy(c->ev[i]);
     delete c;
     return NGP_OK;
@@ -3279,6 +3304,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     const uint32_t cap_mid_max = cap_mid_env < 8u ? 8u : (cap_mid_env > kSpecMaxSamples ? kSpecMaxSamples : cap_mid_env);
     static const uint32_t cap_hi_env = getenv("NGP_SPEC_CAP_HI") ? (uint32_t)atoi(getenv("NGP_SPEC_CAP_HI")) : kSpecMaxSamples;
     const uint32_t cap_hi = cap_hi_env < 8u ? 8u : (cap_hi_env > kSpecMaxSamples ? kSpecMaxSamples : cap_hi_env);
+    const uint32_t call_tag = ++ctx->calls & 0x7FFFu;
     uint32_t ub = N;          // host-side upper bound of n_alive
     uint32_t launched = 0;    // iterations enqueued
     uint32_t known = 0;       // iterations whose resulting status the host has read
@@ -3308,7 +3334,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
                                                            ctx->status_dev + launched % kRing, ctx->seq_base + launched + 1,
                                                            ctx->death_shards + (size_t)cur * kDeathWords, spec_allowed, ctx->alive[cur],
                                                            ctx->backup, ctx->rays_t, weights_sum, depth, image, dbg.sample_hash, ctx->stat_shards,
-                                                           ctx->death_shards + (size_t)(cur ^ 1) * kDeathWords, ra.wave_slots, cap_mid_max, cap_hi);
+                                                           ctx->death_shards + (size_t)(cur ^ 1) * kDeathWords, ra.wave_slots, cap_mid_max, cap_hi, ctx->fin_dev, call_tag);
         launched++;
         launches += 3;
         // consume every status that has already landed; block only when too far ahead
@@ -3355,16 +3381,43 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     }
     rc = check_launch("render_rays");
     if (rc) return rc;
-    if (stats_host || sync) {
+    bool have_fin = false;
+    Ctl fin = {};   // state after the last enqueued iteration (done is sticky)
+    if (stats_host && !sync) {
+        // the finished loop's counters arrive in pinned memory next to the status word the loop above has already seen: a short,
+        // bounded wait for the four tags (they are stored just before that word), then no synchronize and no copy
+        volatile unsigned long long* f = ctx->fin;
+        unsigned long long w[4] = {0, 0, 0, 0};
+        for (uint32_t spin = 0; spin < 200000u && !have_fin; spin++) {
+            bool all = true;
+            for (int i = 0; i < 4; i++) {
+                w[i] = f[i];
+                all = all && (w[i] >> 48) == (0x8000u | call_tag);
+            }
+            have_fin = all;
+            if (!have_fin) __builtin_ia32_pause();
+        }
+        if (have_fin) {
+            fin.samples_marched = w[0] & 0xFFFFFFFFFFFFull;
+            fin.samples_slots = w[1] & 0xFFFFFFFFFFFFull;
+            fin.iters = (uint32_t)((w[2] >> 24) & 0xFFFFFFu);
+            fin.rollbacks = (uint32_t)(w[2] & 0xFFFFFFu);
+            fin.last_n_alive = (uint32_t)((w[3] >> 8) & 0xFFFFFFFFu);
+            fin.last_n_step = (uint32_t)(w[3] & 0xFFu);
+        }
+    }
+    if ((stats_host && !have_fin) || sync) {
         if (hipStreamSynchronize(s) != hipSuccess) {
             set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
             return NGP_ELAUNCH;
         }
-        Ctl fin;   // state after the last enqueued iteration (done is sticky)
         if (hipMemcpy(&fin, ctx->ctl + (launched & 1), sizeof(Ctl), hipMemcpyDeviceToHost) != hipSuccess) {
             set_error("render_rays: %s", hipGetErrorString(hipGetLastError()));
             return NGP_ELAUNCH;
         }
+        have_fin = true;
+    }
+    if (have_fin) {
         if (stats_host) {
             stats_host->samples_marched = fin.samples_marched;
             stats_host->samples_slots = fin.samples_slots;
