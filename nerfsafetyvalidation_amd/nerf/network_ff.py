@@ -63,6 +63,100 @@ class _rgb(Function):
         return g_o, None
 
 
+class _ff_network(Function):
+    """The whole of network_ff.py:55-70 for a training batch as ONE autograd node: the five launches of the forward (hash grid into
+    level planes, sigma FFMLP, sigma / colour-input step, colour FFMLP, rgb step) and the five of the backward, the same kernels with the
+    same operands as the five separate nodes above and in gridencoder / ffmlp (`NeRFNetwork.fused_network_node = False` restores
+    them; the results are bit-identical).  At the reference's 4096 rays per step an optimiser step is host time, and four nodes less
+    each way are a tenth of it."""
+
+    @staticmethod
+    def forward(ctx, x, d, embeddings, sigma_w, color_w, net):
+        import numpy as np
+        from ..gridencoder.grid import _table_for_call
+        lib = _lib.lib()
+        enc, sn, cn = net.encoder, net.sigma_net, net.color_net
+        st = _lib.stream()
+        B = x.shape[0]
+        Bp = B + (-B) % 16
+        L, C, D = enc.num_levels, enc.level_dim, enc.input_dim
+        S, H = float(np.log2(enc.per_level_scale)), enc.base_resolution
+        x01 = ((x + net.bound) / (2 * net.bound)).float().contiguous()
+        d = d.float().contiguous()
+        inference = not any(ctx.needs_input_grad[2:5])        # (grad mode is off inside a Function's forward: ask the node itself)
+        emb16, cells, cell_levels = _table_for_call(embeddings, enc.offsets, B, D, C, L, S, H, enc.gridtype_id, enc.align_corners)
+        emb16 = emb16.contiguous()
+        offs = _lib.host_i32(enc.offsets)
+        dev = x.device
+        planes = torch.empty(L, Bp, C, device=dev, dtype=torch.float16)
+        if Bp != B:
+            planes[:, B:].zero_()
+        _lib.check(lib.ngp_grid_encode_forward_strided(_lib.ptr(x01), _lib.ptr(emb16), offs, _lib.ptr(planes), B, D, C, L, S, H, 0, None,
+                                                       enc.gridtype_id, int(enc.align_corners), _lib.dtype_code(emb16), _lib.ptr(cells), cell_levels,
+                                                       Bp * C, C, st), "grid_encode_forward")
+        sw16, cw16 = sigma_w.detach().to(torch.float16).contiguous(), color_w.detach().to(torch.float16).contiguous()
+        h = torch.empty(Bp, 16, device=dev, dtype=torch.float16)
+        _lib.check(lib.ngp_ffmlp_forward_planes(_lib.ptr(planes), _lib.ptr(sw16), Bp, sn.input_dim, 16, sn.hidden_dim, sn.num_layers, sn.activation,
+                                                sn.output_activation, None, _lib.ptr(h), st), "ffmlp_forward_planes")
+        sigma = torch.empty(B, dtype=torch.float32, device=dev)
+        cin = torch.empty(Bp, 32, dtype=torch.float16, device=dev)
+        _lib.check(lib.ngp_ff_sigma_color_input(_lib.ptr(h), _lib.ptr(d), B, Bp, _lib.ptr(sigma), _lib.ptr(cin), st), "ff_sigma_color_input")
+        o = torch.empty(Bp, 16, device=dev, dtype=torch.float16)
+        _lib.check(lib.ngp_ffmlp_inference(_lib.ptr(cin), _lib.ptr(cw16), Bp, cn.input_dim, 16, cn.hidden_dim, cn.num_layers, cn.activation,
+                                           cn.output_activation, None, _lib.ptr(o), st), "ffmlp_inference")
+        rgb = torch.empty(B, 3, dtype=torch.float16, device=dev)
+        _lib.check(lib.ngp_ff_rgb(_lib.ptr(o), B, _lib.ptr(rgb), st), "ff_rgb")
+        if not inference:
+            ctx.save_for_backward(x01, emb16, planes, sw16, h, cin, cw16, rgb)
+            ctx.cfg = (B, Bp, L, C, D, S, H, enc.gridtype_id, int(enc.align_corners), offs,
+                       (sn.input_dim, sn.hidden_dim, sn.num_layers, sn.activation, sn.output_activation),
+                       (cn.input_dim, cn.hidden_dim, cn.num_layers, cn.activation, cn.output_activation))
+        ctx.set_materialize_grads(False)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        x01, emb16, planes, sw16, h, cin, cw16, rgb = ctx.saved_tensors
+        B, Bp, L, C, D, S, H, gridtype, align, offs, scfg, ccfg = ctx.cfg
+        lib = _lib.lib()
+        st = _lib.stream()
+        dev = h.device
+        want_emb, want_sw, want_cw = ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+
+        def ffmlp_bwd(fn, grad, inputs, w16, cfg, want_inputs):
+            in_dim, hid, layers, act, oact = cfg
+            g_in = torch.empty_like(inputs) if want_inputs else None
+            g_w = torch.empty_like(w16)
+            wbytes = lib.ngp_ffmlp_backward_workspace(Bp, in_dim, hid, layers)
+            work = torch.empty((wbytes + 3) // 4, dtype=torch.float32, device=dev)
+            _lib.check(fn(_lib.ptr(grad), _lib.ptr(inputs), _lib.ptr(w16), None, Bp, in_dim, 16, hid, layers, act, oact, int(want_inputs), None,
+                          _lib.ptr(g_in), _lib.ptr(g_w), _lib.ptr(work), wbytes, st), "ffmlp_backward")
+            return g_in, g_w
+
+        g_cin = g_cw = None
+        if g_rgb is not None:
+            g_o = torch.empty(Bp, 16, dtype=torch.float16, device=dev)
+            _lib.check(lib.ngp_ff_rgb_backward(_lib.ptr(g_rgb.contiguous().half()), _lib.ptr(rgb), B, Bp, _lib.ptr(g_o), st), "ff_rgb_backward")
+            g_cin, g_cw = ffmlp_bwd(lib.ngp_ffmlp_backward, g_o, cin, cw16, ccfg, True)
+        elif want_cw:
+            g_cw = torch.zeros_like(cw16)
+        if g_sigma is None and g_cin is None:
+            return None, None, None, None, (g_cw if want_cw else None), None
+        g_h = torch.empty_like(h)
+        _lib.check(lib.ngp_ff_sigma_color_input_backward(_lib.ptr(h), _lib.ptr(g_sigma.contiguous().float() if g_sigma is not None else None),
+                                                         _lib.ptr(g_cin), B, Bp, _lib.ptr(g_h), st), "ff_sigma_color_input_backward")
+        g_planes, g_sw = ffmlp_bwd(lib.ngp_ffmlp_backward_planes, g_h, planes, sw16, scfg, want_emb)
+        g_emb = None
+        if want_emb:
+            g_emb = torch.zeros_like(emb16)
+            wbytes = lib.ngp_grid_encode_backward_workspace(B, D, C, L, _lib.dtype_code(emb16))
+            work = torch.empty(wbytes, dtype=torch.uint8, device=dev) if wbytes else None
+            _lib.check(lib.ngp_grid_encode_backward_strided(_lib.ptr(g_planes), _lib.ptr(x01), _lib.ptr(emb16), offs, _lib.ptr(g_emb), B, D, C, L, S, H,
+                                                            0, None, None, gridtype, align, _lib.dtype_code(emb16), _lib.ptr(work), wbytes, Bp * C, C, st),
+                       "grid_encode_backward")
+        return None, None, g_emb, (g_sw if want_sw else None), (g_cw if want_cw else None), None
+
+
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
                  num_layers_color=3, hidden_dim_color=64, bound=1, **kwargs):
@@ -81,6 +175,7 @@ class NeRFNetwork(NeRFRenderer):
                                num_layers=self.num_layers_color)
         self._fused_cache = None
         self.fused_heads = True       # (this build) forward(): one kernel per direction between the FFMLPs; False = the torch chain
+        self.fused_network_node = True   # (this build) ... and the five launches each way as one autograd node (_ff_network)
 
     def _color_input(self, d, geo_feat):
         d = self.encoder_dir(d)
@@ -100,6 +195,10 @@ class NeRFNetwork(NeRFRenderer):
                 and self.encoder.level_dim == 2 and self.sigma_net.hidden_dim == 64 and 2 <= self.sigma_net.num_layers <= 4)
 
     def forward(self, x, d):
+        if self._fused_heads_ok(x, d) and self.fused_network_node and self.sigma_net.hidden_dim == 64 and self.color_net.hidden_dim == 64 \
+                and self.encoder.embeddings.dtype == torch.float32 and _lib.lib().ngp_ffmlp_backward_recomputes(32, 64, self.sigma_net.num_layers) \
+                and _lib.lib().ngp_ffmlp_backward_recomputes(32, 64, self.color_net.num_layers):
+            return _ff_network.apply(x, d, self.encoder.embeddings, self.sigma_net.weights, self.color_net.weights, self)
         if self._fused_heads_ok(x, d):
             # network_ff.py:55-70 with the tensors between the kernels in the layout the producing kernel writes: the sigma FFMLP reads the
             # encoder's level planes in place (row padding included) and hands back the gradient the same way; the elementwise steps

@@ -59,8 +59,9 @@ def test_network_ff_forward_fused_elementwise_steps_equal_the_torch_chain(device
     d = torch.nn.functional.normalize(torch.randn(B, 3, device=device), dim=-1)
     gs, gc = torch.randn(B, device=device), torch.randn(B, 3, device=device)
     out = {}
-    for fused in (True, False):
-        net.fused_heads = fused
+    for fused in ("node", True, False):         # one autograd node / five nodes with the one-kernel elementwise steps / the torch chain
+        net.fused_heads = bool(fused)
+        net.fused_network_node = fused == "node"
         net.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16):
             sigma, rgb = net(x, d)
@@ -68,6 +69,10 @@ def test_network_ff_forward_fused_elementwise_steps_equal_the_torch_chain(device
         ((sigma * gs).sum() * 64 + (rgb.float() * gc).sum() * 64).backward()
         out[fused] = (sigma.detach(), rgb.detach(), net.sigma_net.weights.grad.clone(), net.color_net.weights.grad.clone(),
                       net.encoder.embeddings.grad.clone())
+    for i in range(4):
+        assert torch.equal(out["node"][i], out[True][i]), i
+    scale = float(out[True][4].abs().max())
+    assert float((out["node"][4] - out[True][4]).abs().max()) <= 4e-3 * scale
     a, b = out[True], out[False]
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):       # the colour net's input itself (SH values rounded once from fp32)
         from nerfsafetyvalidation_amd.nerf.network_ff import _sigma_color_input
@@ -83,6 +88,14 @@ def test_network_ff_forward_fused_elementwise_steps_equal_the_torch_chain(device
     scale = float(b[4].abs().max())
     assert scale > 0 and float((a[4] - b[4]).abs().max()) <= 4e-3 * scale
     # sigma alone (what a density-only loss differentiates): the colour input's gradient is absent, not zero-filled by hand
+    net.fused_network_node = True
+    net.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        sigma, _ = net(x, d)
+    (sigma * gs).sum().backward()
+    g_node = net.sigma_net.weights.grad.clone()
+    assert net.color_net.weights.grad is None or not bool(net.color_net.weights.grad.any())
+    net.fused_network_node = False
     net.fused_heads = True
     net.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.float16):
@@ -94,7 +107,7 @@ def test_network_ff_forward_fused_elementwise_steps_equal_the_torch_chain(device
     with torch.autocast("cuda", dtype=torch.float16):
         sigma, _ = net(x, d)
     (sigma * gs).sum().backward()
-    assert torch.equal(g_fused, net.sigma_net.weights.grad)
+    assert torch.equal(g_fused, net.sigma_net.weights.grad) and torch.equal(g_node, g_fused)
 
 
 def test_full_frame_training_step_forms_agree(device, monkeypatch):
