@@ -157,6 +157,93 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(const float* __res
     }
 }
 
+// The count pass of a SMALL batch (the reference's 4096 rays per step: 64 waves, each the latency chain of its slowest ray -- hundreds of
+// dependent probes; 0.35 ms of a 1.6 ms training step) with one WAVE per ray.  With dt_gamma == 0 every t the march visits lies on the
+// lattice t0, t0 + dt, (t0 + dt) + dt, ... of the sequential additions, and inside one binade (above Dda::t_fast_min) those additions
+// are exact: point k is fmaf(k, d, t) with d = fl(t + dt) - t (skip_const_dt's argument).  Lane l therefore evaluates the probe AT
+// lattice point l of the current window -- the same pure function of t the sequential march evaluates, returning whether the cell is
+// occupied and where the march goes next from there (one step for a sample, the cell / block exit for an empty cell) -- and the wave
+// then follows the chain 0 -> next(0) -> next(next(0)) ... through the window from registers: the points on it are exactly the ones
+// the sequential march visits, the occupied ones among them its samples, in order.  Windows end at the binade (the step d changes
+// there: the point after it is evaluated alone, as the sequential march would), at `far`, and at the step budget.  Same (t, dt) trace,
+// same counts, bit for bit; the write pass replays the trace.
+__global__ void __launch_bounds__(kBlock) k_march_train_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                   const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
+                                                                   uint32_t N, uint32_t C, uint32_t H, const float* __restrict__ nears,
+                                                                   const float* __restrict__ fars, uint32_t perturb, Pcg32 rng,
+                                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ block_sums, TrainLin tl,
+                                                                   float2* __restrict__ trace) {
+    __shared__ uint32_t coarse_lds[kTrainCoarseBytes / 4];
+    for (uint32_t i = threadIdx.x; i < tl.coarse_words; i += kBlock) coarse_lds[i] = tl.coarse[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // one wave per ray
+    if (n >= N) return;
+    Dda s;
+    s.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
+    s.init_lin(tl.lin, tl.logH, true);
+    const float far = fars[n];
+    float t = nears[n];
+    if (perturb) {
+        rng.advance((int64_t)n);
+        t += s.dt_min * rng.next_float();
+    }
+    uint32_t num_steps = 0;
+    float2* out = trace + (size_t)n * max_steps;
+    while (t < far && num_steps < max_steps) {
+        // lattice point `lane` of this window; valid while it stays in t's binade (and the exact regime) and before `far`
+        const float t1 = t + s.dt_c, d = t1 - t;
+        const float p = lane == 0 ? t : fmaf((float)lane, d, t);
+        const bool exact = t >= s.t_fast_min && ((__float_as_uint(p) ^ __float_as_uint(t)) >> 23) == 0;
+        const bool valid = lane == 0 || (exact && p < far);
+        float nxt = p, x, y, z, dt;
+        bool occ = false;
+        if (valid) {
+            occ = s.probe_lin(nxt, x, y, z, dt, coarse_lds);      // empty: nxt moves on to where the march continues
+            if (occ) nxt = p + dt;
+        }
+        // index of `nxt` in the window (64: it leaves the window, or is not one of its points): exact when it is a lattice point
+        uint32_t j = 64;
+        if (valid) {
+            const float q = rintf((nxt - t) * __builtin_amdgcn_rcpf(d));
+            if (q >= 1.0f && q < 64.0f && fmaf(q, d, t) == nxt) j = (uint32_t)q;
+        }
+        const unsigned long long vmask = __ballot(valid), omask = __ballot(occ);
+        // follow the chain from point 0 (registers only: one v_readlane per visited point)
+        unsigned long long visited = 0ull;
+        uint32_t cur = 0;
+        float t_exit = t;
+        for (int guard = 0; guard < 64; guard++) {        // (the chain is strictly increasing: at most 64 points)
+            visited |= 1ull << cur;
+            const uint32_t jn = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)cur);
+            if (jn >= 64u || !((vmask >> jn) & 1ull)) {
+                t_exit = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(nxt), (int)cur));
+                break;
+            }
+            cur = jn;
+        }
+        // the samples of the window, in order, up to the step budget (the march stops after the sample that fills it)
+        unsigned long long emit = visited & omask;
+        const uint32_t room = max_steps - num_steps;
+        uint32_t cnt = (uint32_t)__popcll(emit);
+        if (cnt > room) {
+            // keep the first `room` samples: clear the higher ones
+            unsigned long long e = emit;
+            for (uint32_t k = 0; k < room; k++) e &= e - 1ull;      // (rare: a ray that fills its budget)
+            emit &= ~e;
+            cnt = room;
+        }
+        if ((emit >> lane) & 1ull) out[num_steps + (uint32_t)__popcll(emit & ((1ull << lane) - 1ull))] = make_float2(p, dt);
+        num_steps += cnt;
+        t = t_exit;
+        if (cnt == room) break;
+    }
+    if (lane == 0) {
+        counts[n] = num_steps;
+        if (num_steps) atomicAdd(&block_sums[n / kBlock], num_steps);
+    }
+}
+
 // Phase B: one block turns block_sums into exclusive offsets (in place) and bumps the
 // reference's two counters the way its atomics leave them.  base[0..1] receive the
 // counter values BEFORE this call (the slot / row bases).
@@ -293,6 +380,60 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(const float* __res
             pdir[3 * k] = s.dx; pdir[3 * k + 1] = s.dy; pdir[3 * k + 2] = s.dz;
             pdel[2 * k] = bd[2 * k]; pdel[2 * k + 1] = bd[2 * k + 1];
         }
+}
+
+// The write pass of a small batch with one wave per ray: the count pass left the ray's (t, dt) trace, so sample i is lane i's -- position,
+// direction and the two deltas (deltas[1] = (t_i + dt_i) - (t_{i-1} + dt_{i-1}), from the march's start for the first) are independent
+// of each other.  Slots as in k_march_train_write: exclusive prefix of the counts in ray order (block offset + the counts of the rays
+// before this one in its 256-ray block).
+__global__ void __launch_bounds__(kBlock) k_march_train_write_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound,
+                                                                   uint32_t max_steps, uint32_t N, uint32_t M, const float* __restrict__ nears,
+                                                                   uint32_t perturb, Pcg32 rng, const uint32_t* __restrict__ counts,
+                                                                   const uint32_t* __restrict__ block_offsets, const uint32_t* __restrict__ base,
+                                                                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                                                                   int32_t* __restrict__ rays, const float2* __restrict__ trace) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t num_steps = counts[n];
+    const uint32_t blk = n / kBlock, first = blk * kBlock;
+    uint32_t before = 0;
+    for (uint32_t i = first + lane; i < n; i += 64) before += counts[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    const uint32_t point_index = base[0] + block_offsets[blk] + before;
+    const uint32_t ray_index = base[1] + n;
+    if (lane == 0 && ray_index < N) {
+        rays[ray_index * 3] = (int32_t)n;
+        rays[ray_index * 3 + 1] = (int32_t)point_index;
+        rays[ray_index * 3 + 2] = (int32_t)num_steps;
+    }
+    if (num_steps == 0 || point_index + num_steps >= M) return;
+    const float ox = rays_o[(size_t)n * 3], oy = rays_o[(size_t)n * 3 + 1], oz = rays_o[(size_t)n * 3 + 2];
+    const float dx = rays_d[(size_t)n * 3], dy = rays_d[(size_t)n * 3 + 1], dz = rays_d[(size_t)n * 3 + 2];
+    float t_start = nears[n];
+    if (perturb) {
+        const float SQRT3 = 1.7320508075688772f;
+        rng.advance((int64_t)n);
+        t_start += (2 * SQRT3 / (float)max_steps) * rng.next_float();
+    }
+    const float2* tr = trace + (size_t)n * max_steps;
+    for (uint32_t i = lane; i < num_steps; i += 64) {
+        const float2 td = tr[i];
+        float last_t = t_start;
+        if (i > 0) {
+            const float2 pv = tr[i - 1];
+            last_t = pv.x + pv.y;
+        }
+        const float t_after = td.x + td.y;
+        const size_t row = (size_t)point_index + i;
+        xyzs[row * 3] = clampf(fmaf(td.x, dx, ox), -bound, bound);
+        xyzs[row * 3 + 1] = clampf(fmaf(td.x, dy, oy), -bound, bound);
+        xyzs[row * 3 + 2] = clampf(fmaf(td.x, dz, oz), -bound, bound);
+        dirs[row * 3] = dx; dirs[row * 3 + 1] = dy; dirs[row * 3 + 2] = dz;
+        deltas[row * 2] = td.y;
+        deltas[row * 2 + 1] = t_after - last_t;
+    }
 }
 
 // Four consecutive steps of a ray per load: a lane walks its own slab (the neighbouring lane's is ~1 KB away), so every load
@@ -697,7 +838,12 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
         tl.coarse = (const uint32_t*)coarse;
         tl.coarse_words = (uint32_t)(cells / 64 / 32);
         tl.logH = logH;
-        if (trace)
+        static const bool wave_off = getenv("NGP_MARCH_TRAIN_NO_WAVE") != nullptr;      // diagnostics: the one-lane-per-ray count pass
+        if (trace && dt_gamma == 0.0f && !wave_off) {
+            (void)hipMemsetAsync(block_sums, 0, (size_t)nblocks * sizeof(uint32_t), s);
+            k_march_train_count_wave<<<div_up(N, kBlock / 64), kBlock, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, perturb, rng,
+                                                                              counts, block_sums, tl, trace);
+        } else if (trace)
             k_march_train_count<true, true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, perturb,
                                                                        rng, counts, block_sums, tl, trace);
         else
@@ -708,7 +854,11 @@ int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                                                                      counts, block_sums, tl, nullptr);
     }
     k_march_train_scan<<<1, 1024, 0, s>>>(block_sums, nblocks, N, counter, base);
-    if (lin && trace)
+    static const bool wave_off2 = getenv("NGP_MARCH_TRAIN_NO_WAVE") != nullptr;
+    if (lin && trace && dt_gamma == 0.0f && !wave_off2)
+        k_march_train_write_wave<<<div_up(N, kBlock / 64), kBlock, 0, s>>>(rays_o, rays_d, bound, max_steps, N, M, nears, perturb, rng, counts, block_sums,
+                                                                          base, xyzs, dirs, deltas, rays, trace);
+    else if (lin && trace)
         k_march_train_write<true, true><<<nblocks, kBlock, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, perturb, rng,
                                                                    counts, block_sums, base, xyzs, dirs, deltas, rays, tl, trace);
     else if (lin)
