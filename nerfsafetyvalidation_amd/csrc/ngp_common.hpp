@@ -159,7 +159,7 @@ struct Dda {
     uint32_t logH;
     int sx, sy, sz;     // 1 where the direction component is >= +0 (signf == +1), else 0
     float two_rH;
-    float jump_guard;   // absolute part of the rounding allowance of a block-exit time (see jump_block)
+    float jump_guard;   // rounding allowance of a block-exit time per unit of |1/d| of the axis it is taken on (see jump_block)
     bool block_jump;    // leave empty 4x4x4 blocks in one step (A/B switch)
     const uint8_t* grid;
 
@@ -199,7 +199,7 @@ struct Dda {
         sy = (int)((__float_as_uint(dy) >> 31) ^ 1u);
         sz = (int)((__float_as_uint(dz) >> 31) ^ 1u);
         two_rH = 2.0f * rH;
-        jump_guard = (fabsf(rdx) + fabsf(rdy) + fabsf(rdz)) * bound * 9.5367431640625e-7f;   // 2^-20
+        jump_guard = bound * 9.5367431640625e-7f;   // 2^-20: eight ulps of a coordinate
     }
 
     // `do { t += dt_c; } while (t < tt);` (:395-403 with a constant step) without the loop.  Inside one binade above the tie
@@ -316,14 +316,29 @@ struct Dda {
             if (fmaxf(mx, fmaxf(my, mz)) < 0.5f) return false;
         }
         const float tx = fmaf(bx, mip_bound, -x) * rdx, ty = fmaf(by, mip_bound, -y) * rdy, tz = fmaf(bz, mip_bound, -z) * rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        const float tmin = fminf(tx, fminf(ty, tz));
+        const float tt = t + fmaxf(0.0f, tmin);
         const float t1 = t + dt_c;
         if (!(t1 < tt)) return false;
         const float d = t1 - t;
         float t2 = fmaf(ceilf((tt - t1) * __builtin_amdgcn_rcpf(d)), d, t1);
         if (t2 < tt) t2 += d;
         else if (t2 - d >= tt) t2 -= d;
-        const float guard = fmaf(t2, 9.5367431640625e-7f, jump_guard);
+        // The allowance: a face-crossing time (face - x) / d carries the coordinate's rounding times |1/d| -- e_a = |1/d_a| * 8 ulp(bound),
+        // sixteen times what either side's evaluation can be off by.  Only axes that can be the minimum count: one whose crossing lies
+        // beyond the minimum by more than both allowances is not the exit face here, nor in the reference's last cell (its own value of
+        // that crossing differs from this one by less than e_a / 8).  A ray almost parallel to an axis (|1/d| in the thousands: two or
+        // three pixel columns of a frame) used to have every jump refused on that axis' account and walked 200 cells of empty space
+        // one by one -- the launch-wide march lasts as long as its slowest ray.  (infinite / NaN crossings -- d_a = 0 -- fail every
+        // comparison below, as they are ignored by fminf on both sides.)
+        const float ex = fabsf(rdx) * jump_guard, ey = fabsf(rdy) * jump_guard, ez = fabsf(rdz) * jump_guard;
+        const float em = tmin == tx ? ex : (tmin == ty ? ey : ez);
+        const float lim = tmin + em;
+        float ga = em;
+        if (tx - ex <= lim) ga = fmaxf(ga, ex);
+        if (ty - ey <= lim) ga = fmaxf(ga, ey);
+        if (tz - ez <= lim) ga = fmaxf(ga, ez);
+        const float guard = fmaf(t2, 9.5367431640625e-7f, ga);
         const bool clear = (t2 - tt) > guard && (tt - (t2 - d)) > guard;   // false for NaN / infinite allowances as well
         const bool same_binade = ((__float_as_uint(t2) ^ __float_as_uint(t)) >> 23) == 0;
         if (!(clear && same_binade && t >= t_fast_min)) return false;

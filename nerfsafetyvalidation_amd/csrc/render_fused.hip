@@ -2129,6 +2129,7 @@ struct RenderArgs {
     uint32_t wave_slots;              // waves the chip holds for this launch (item_width)
     uint32_t n_rays;                  // N: the reference's n_step = clamp(N // n_alive, 1, 8)
     uint32_t pre_verdict;             // k_march_ahead counts the rays whose march runs out per iteration (truncate_launch); 0: diagnostics
+    uint32_t wave_march_max;          // launches of at most this many rays march one WAVE per ray (march_ahead_wave); 0: never
 };
 
 // Work items of k_render_iter: W consecutive entries of the alive list, one wave each.  64 while the list fills the chip's wave slots
@@ -2201,15 +2202,106 @@ __device__ __forceinline__ void dump_row(const RenderArgs& ra, uint32_t entry, i
 // Dda, same restart of the march at the iteration boundaries of a multi-iteration launch (from the re-accumulated rays_t), same jitter.
 // LIN: power-of-two grid with the linear copies of the occupancy bits (Dda::probe_lin); otherwise the Morton-order originals
 // ------------------------------------------------------------------------------------------
+// The same march with one WAVE per ray, for the launches of a frame's tail: a few thousand rays, up to 32 samples each -- a lane per ray
+// leaves the chip empty and the launch lasts as long as one ray's chain of dependent probes (60-80 us).  With a constant step
+// (dt_gamma == 0) the march's positions inside one binade of t are the lattice t + k * d, d = fl(t + dt) - t (Dda::skip_const_dt): lane k
+// probes lattice point k of a 64-point window at once, each probe says where the march goes from there (the next point if the cell is
+// occupied -- a sample -- or the first point beyond the empty cell / block), and the wave follows that chain from point 0 through
+// registers (v_readlane), collecting the samples it visits.  Points the chain cannot vouch for (another binade, t below the exact regime,
+// a continuation that is not a lattice point) end the window: the march continues from the exact t the lane-per-ray form would have.
+// Same samples, same (t, dt) bits, same deltas -- k_render_iter cannot tell the two forms apart.
+__device__ __forceinline__ void march_ahead_wave(const RenderArgs& ra, float bound, const Ctl& ctl, const uint32_t* coarse) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (entry >= ctl.n_alive) return;
+    const uint32_t n_step = ctl.n_step, spec = ctl.spec;
+    const int32_t ray = ra.alive_in[entry];
+    Dda dda;
+    dda.init(ra.rays_o + (size_t)ray * 3, ra.rays_d + (size_t)ray * 3, ra.bitfield, bound, 0.0f, ra.max_steps, ra.cascade, ra.grid_size);
+    dda.init_lin(ra.bitfield_lin, ra.log_grid, ra.block_jump != 0);
+    const float t_c = ra.rays_t[ray], far = ra.fars[ray];
+    float t_march = t_c;
+    if (ra.perturb) {
+        Pcg32 rng = ra.rng;
+        rng.advance((int64_t)entry);
+        t_march += dda.dt_min * rng.next_float();
+    }
+    float last_m = t_march, geo_tc = t_c;
+    uint32_t emitted = 0, rounds = 0;
+    float2* out = ra.march_samples + ((size_t)(entry >> 6) * n_step) * 64 + (entry & 63u);
+    while (t_march < far && emitted < n_step) {
+        rounds++;
+        const float t1 = t_march + dda.dt_c, d = t1 - t_march;
+        const float p = lane == 0 ? t_march : fmaf((float)lane, d, t_march);
+        const bool exact = t_march >= dda.t_fast_min && ((__float_as_uint(p) ^ __float_as_uint(t_march)) >> 23) == 0;
+        const bool valid = lane == 0 || (exact && p < far);
+        float nxt = p, x, y, z, dt = 0.0f;
+        bool occ = false;
+        if (valid) {
+            occ = dda.probe_lin(nxt, x, y, z, dt, coarse);     // empty: nxt moves on to where the march continues
+            if (occ) nxt = p + dt;
+        }
+        uint32_t j = 64;                                       // index of `nxt` in the window, if it is one of its points
+        if (valid) {
+            const float q = rintf((nxt - t_march) * __builtin_amdgcn_rcpf(d));
+            if (q >= 1.0f && q < 64.0f && fmaf(q, d, t_march) == nxt) j = (uint32_t)q;
+        }
+        const unsigned long long vmask = __ballot(valid), omask = __ballot(occ);
+        // samples until the iteration boundary inside the launch (march_rays starts again from rays_t there), or the end of the launch
+        const uint32_t room = spec ? spec - emitted % spec : n_step - emitted;
+        unsigned long long emit = 0ull;
+        uint32_t cur = 0, cnt = 0;
+        float t_next = t_march;
+        for (int guard = 0; guard < 64; guard++) {             // (the chain is strictly increasing: at most 64 points)
+            const float to = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(nxt), (int)cur));
+            if ((omask >> cur) & 1ull) {
+                emit |= 1ull << cur;
+                const float d1 = to - last_m;                  // deltas[1] of this sample (:791-793)
+                last_m = to;
+                geo_tc += d1;
+                if (++cnt == room) { t_next = to; break; }
+            }
+            const uint32_t jn = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)cur);
+            if (jn >= 64u || !((vmask >> jn) & 1ull)) { t_next = to; break; }
+            cur = jn;
+        }
+        if ((emit >> lane) & 1ull) out[(size_t)(emitted + (uint32_t)__popcll(emit & ((1ull << lane) - 1ull))) * 64] = make_float2(p, dt);
+        emitted += cnt;
+        t_march = t_next;
+        if (spec && cnt == room) {                             // iteration boundary: from the re-accumulated rays_t, with last_t = t
+            t_march = geo_tc;
+            last_m = geo_tc;
+        }
+    }
+    if (lane != 0) return;
+    if (ra.stamps) {   // diagnostics: a window counts as one probe of the ray
+        atomicAdd(ra.stamps + 4, (unsigned long long)rounds);
+        atomicAdd(ra.stamps + 5, (unsigned long long)rounds * 64ull);
+        atomicAdd(ra.stamps + 6, 1ull);
+        atomicMax(ra.stamps + 7, (unsigned long long)rounds);
+    }
+    if (spec && ra.pre_verdict && emitted < n_step)
+        atomicAdd(ra.death_shards + (size_t)kDeathShards * kSpecK + (blockIdx.x % kDeathShards) * kSpecK + emitted / spec, 1u);
+    bool slow = false;
+    if (ra.sort_slow && emitted == n_step) slow = geo_tc < far && dda.coarse_empty_at_lin(geo_tc, coarse);
+    ra.march_counts[entry] = (uint8_t)(emitted | (slow ? 128u : 0u));
+}
+
 template <bool LIN>
 __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound) {
     const Ctl ctl = *ra.ctl;
     if (ctl.done) return;
     const uint32_t n_alive = ctl.n_alive, n_step = ctl.n_step, spec = ctl.spec;
+    const bool by_wave = LIN && n_alive <= ra.wave_march_max;
+    if (blockIdx.x * (by_wave ? 4u : 256u) >= n_alive) return;
     __shared__ uint32_t coarse_lds[kCoarseMaxBytes / 4];
     for (uint32_t i = threadIdx.x; i < ra.coarse_words; i += blockDim.x) coarse_lds[i] = ra.coarse[i];
     __syncthreads();
     const uint32_t* coarse = ra.coarse_words ? coarse_lds : nullptr;
+    if (LIN && by_wave) {
+        march_ahead_wave(ra, bound, ctl, coarse);
+        return;
+    }
     const uint32_t entry = blockIdx.x * blockDim.x + threadIdx.x;
     if (entry >= n_alive) return;
     const int32_t ray = ra.alive_in[entry];
@@ -2228,9 +2320,11 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
     uint32_t emitted = 0;
     float2* out = ra.march_samples + ((size_t)(entry >> 6) * n_step) * 64 + (entry & 63u);
     float x, y, z, dt;
-    uint32_t probes = 0;                 // diagnostics (ra.stamps): probes of this lane
+    uint32_t probes = 0, probes_coarse_empty = 0, probes_fine_empty = 0;   // diagnostics (ra.stamps): probes of this lane
     while (t_march < far && emitted < n_step) {
         probes++;
+        const bool diag_ce = LIN && ra.stamps && dda.coarse_empty_at_lin(t_march, coarse);
+        const uint32_t emitted_before = emitted;
         if (LIN ? dda.probe_lin(t_march, x, y, z, dt, coarse) : dda.probe(t_march, x, y, z, dt, coarse)) {
             out[(size_t)emitted * 64] = make_float2(t_march, dt);
             t_march += dt;
@@ -2243,6 +2337,7 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
                 last_m = geo_tc;
             }
         }
+        if (ra.stamps && emitted == emitted_before) { if (diag_ce) probes_coarse_empty++; else probes_fine_empty++; }
     }
     // Rays whose next march begins inside an empty 4x4x4 block are about to skip through empty space (tens of DDA probes) while the
     // others take one probe per sample: k_render_iter groups them into their own chunks (a scheduling decision only).  The flag is
@@ -2260,6 +2355,14 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
             atomicAdd(ra.stamps + 5, (unsigned long long)sm);
             atomicAdd(ra.stamps + 6, 1ull);
             atomicMax(ra.stamps + 7, (unsigned long long)mx);
+        }
+        // [14] probes that found their 4x4x4 block empty, [15] probes in an occupied block that found their cell empty
+        uint32_t ce = probes_coarse_empty, fe = probes_fine_empty;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { ce += (uint32_t)__shfl_xor((int)ce, off, 64); fe += (uint32_t)__shfl_xor((int)fe, off, 64); }
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) {
+            atomicAdd(ra.stamps + 14, (unsigned long long)ce);
+            atomicAdd(ra.stamps + 15, (unsigned long long)fe);
         }
     }
     if (spec && ra.pre_verdict) {     // the iteration of this launch in which the ray's march runs out (truncate_launch); wave-aggregated, sharded counters
@@ -2974,6 +3077,7 @@ struct DebugState {
     bool pre_verdict_off() const { return (flags & 16384) != 0; }
     bool narrow_items_off() const { return (flags & 32768) != 0; }
     bool prefix_replay_off() const { return (flags & 65536) != 0; }
+    bool wave_march_off() const { return (flags & 131072) != 0; }
     uint32_t spec_safety_x2() const { return ((uint32_t)flags >> 9) & 15u; }   // 0: kSpecSafetyX2
     uint32_t shrink() const { return ((uint32_t)flags >> 4) & 15u; }
 };
@@ -3235,6 +3339,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.wave_slots = dbg.narrow_items_off() ? 0u : (env ? (uint32_t)atoi(env) : (uint32_t)ctx->num_cu * 16u);
         static const bool no_pre = getenv("NGP_NO_PRE_VERDICT") != nullptr;   // diagnostics: every multi-iteration launch runs as planned
         ra.pre_verdict = (no_pre || dbg.pre_verdict_off()) ? 0u : 1u;
+        static const char* wm = getenv("NGP_WAVE_MARCH_MAX");    // diagnostics (A/B timing): 0 = a lane per ray always
+        ra.wave_march_max = (dbg.wave_march_off() || dt_gamma != 0.0f) ? 0u : (wm ? (uint32_t)atoi(wm) : (uint32_t)ctx->num_cu * 64u);
     }
     ra.backup = ctx->backup;
     ra.march_samples = ctx->march_samples; ra.march_counts = ctx->march_counts;
@@ -3322,7 +3428,10 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.death_shards = ctx->death_shards + (size_t)cur * kDeathWords;
         {
             ProfScope pm("k_march_ahead", s, 0);  // per-launch events only when ngp_prof_enable(1)
-            if (lin) k_march_ahead<true><<<div_up(ub ? ub : 1, 256), 256, 0, s>>>(ra, na.bound);
+            // (one wave per ray when the launch turns out to have at most wave_march_max rays: four rays per block)
+            const uint32_t by_wave = div_up(ub < ra.wave_march_max ? ub : ra.wave_march_max, 4);
+            const uint32_t by_lane = div_up(ub ? ub : 1, 256);
+            if (lin) k_march_ahead<true><<<by_lane > by_wave ? by_lane : by_wave, 256, 0, s>>>(ra, na.bound);
             else k_march_ahead<false><<<div_up(ub ? ub : 1, 256), 256, 0, s>>>(ra, na.bound);
         }
         {
@@ -3363,6 +3472,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
             }
             known++;
             ub = (uint32_t)w & 0x7FFFFFFFu;
+            static const bool trace_sched = getenv("NGP_TRACE_SCHEDULE") != nullptr;   // diagnostics: the alive count after every launch
+            if (trace_sched) fprintf(stderr, "[ngp] call %u launch %u: n_alive %u%s\n", call_tag, known, ub, ((w >> 31) & 1ull) ? " done" : "");
             if ((w >> 31) & 1ull) { done = true; break; }
         }
         if (launched > 2u * max_steps + 16u) {  // cannot happen: every launch advances step by >= 1 or is the rollback of one that did

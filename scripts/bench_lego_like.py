@@ -12,7 +12,7 @@ from nerfsafetyvalidation_amd import _lib
 if os.environ.get("NGP_DBG_FLAGS"):
     _lib.lib().ngp_debug_disable_march_queue(int(os.environ["NGP_DBG_FLAGS"]))
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 800
-CONFIGS = ((1, 3.2),) if (len(sys.argv) > 2 and sys.argv[2] == "lego") else ((1, 3.2), (2, 1.5))
+CONFIGS = {"lego": ((1, 3.2),), "b2": ((2, 1.5),)}.get(sys.argv[2] if len(sys.argv) > 2 else "", ((1, 3.2), (2, 1.5)))
 for bound, radius in CONFIGS:
     sc = StonehengeScene(H=H, W=W, bound=bound, radius=radius)
     model = sc.build_model(dev)

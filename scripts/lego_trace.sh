@@ -1,9 +1,11 @@
-# kernel timeline of one Lego-like frame (BASELINE configs[3]: bound 1, cameras at r = 3.2): per-launch durations and gaps
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/ktl && mkdir -p gpurun_out
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ktl -- python scripts/bench_lego_like.py 800 lego > gpurun_out/ktl.log 2>&1
-python - <<'PY'
-import csv, glob
-tr = list(csv.DictReader(open(sorted(glob.glob('gpurun_out/ktl/*/*kernel_trace.csv'))[-1])))
+# kernel timeline of one frame, one at a time: per-launch durations and gaps.  `bash scripts/lego_trace.sh lego` = BASELINE configs[3]-like
+# (bound 1, cameras at r = 3.2), `bash scripts/lego_trace.sh b2` = the bound-2 bench frame
+WHICH=${1:-lego}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/ktl_$WHICH && mkdir -p gpurun_out
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ktl_$WHICH -- python scripts/bench_lego_like.py 800 $WHICH > gpurun_out/ktl_$WHICH.log 2>&1
+python - $WHICH <<'PY'
+import csv, glob, sys
+tr = list(csv.DictReader(open(sorted(glob.glob(f'gpurun_out/ktl_{sys.argv[1]}/*/*kernel_trace.csv'))[-1])))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(tr) if 'k_render_init' in r['Kernel_Name']]
 fr = tr[idx[10]:idx[11]]          # frame number 10 (one at a time)

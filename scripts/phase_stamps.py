@@ -21,6 +21,7 @@ with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
 b = buf.cpu().tolist(); tot = sum(b[:4])
 for n, v in zip(['march', 'encode+mlp tiles', 'composite', 'compaction+barrier'], b[:4]): print(f'{n:22s} {v:16d} {100*v/tot:6.2f} %')
 print(f"k_march_ahead waves {b[6]}: mean probes per lane and launch {b[5]/max(1,b[6])/64:.2f}, mean of per-wave max {b[4]/max(1,b[6]):.2f}  -> lane utilisation {b[5]/max(1,64*b[4]):.3f}; slowest lane of all launches {b[7]} probes")
+print(f"k_march_ahead probes: {b[5]} = samples {b[5]-b[14]-b[15]} + empty 4x4x4 blocks {b[14]} + empty cells in occupied blocks {b[15]}")
 print(f"tiles {b[10]}: mean fill {b[11]/max(1,b[10]):.2f}/16; cycles per tile: encode+sigma {b[8]/max(1,b[10]):.0f}, colour {b[9]/max(1,b[10]):.0f}; whole tile phase per tile {b[1]/max(1,b[10]):.0f}")
 import ctypes as C
 ms, n, u = C.c_double(), C.c_uint64(), C.c_double()

@@ -245,7 +245,8 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
         # rays listed in 4x4-pixel tiles) on top of everything
         # ... / 4: no slow-ray grouping and 6: no coarse filter either -- the alive list stays in reference order and the last-iteration
         # tensors are written slot-major WHILE launches cover several iterations (the combination of the bound >= 4 scenes)
-        for flags in (0, 1, 8, 256, 4, 6, "tiles"):
+        # 131072: one lane per ray in every launch (frames this small otherwise march one WAVE per ray, lattice windows of 64 points)
+        for flags in (0, 1, 8, 256, 4, 6, 131072, 131072 | 1, "tiles"):
             lib.ngp_debug_disable_march_queue(0 if flags == "tiles" else flags)
             h = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(h.data_ptr())
@@ -258,7 +259,7 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
         lib.ngp_debug_set_sample_hash(None)
         lib.ngp_debug_disable_march_queue(0)
     assert sc.W % 4 == 0 and N % (4 * sc.W) == 0      # (the hint is only taken for whole rows of tiles)
-    for flags in (1, 8, 256, 4, 6, "tiles"):
+    for flags in (1, 8, 256, 4, 6, 131072, 131072 | 1, "tiles"):
         assert torch.equal(outs[0][0], outs[flags][0]), flags
         assert torch.equal(outs[0][1], outs[flags][1]), flags
         assert torch.equal(outs[0][3], outs[flags][3]) and torch.equal(outs[0][4], outs[flags][4]), flags   # last-iteration tensors
@@ -331,6 +332,65 @@ def test_multi_iteration_launch_is_verified_and_replayed(setup, device):
         assert torch.equal(outs[flags][0], outs[256][0])
         for key in ("samples_marched", "samples_slots", "iterations"):
             assert outs[flags][1][key] == outs[256][1][key], (flags, key)
+
+
+def test_rays_almost_parallel_to_an_axis_leave_empty_blocks_in_one_step(setup, device):
+    """A direction component of 1e-3 or less (the two or three pixel columns of a frame where a component changes sign) puts |1/d| in the
+    thousands: the block-exit allowance used to count every axis and refused all jumps for such rays, which then walked the empty
+    space cell by cell and set the duration of the launch-wide march.  The allowance now counts the axes that can be the exit face.
+    Sample sequences (hashes), images and counters equal the cell walk's (flag 1) in both march forms, components of exactly 0 and
+    -0 included; and the jumps ARE taken (probe count of the lane-per-ray form)."""
+    from nerfsafetyvalidation_amd import _lib
+    sc = setup[0]
+    model = sc.build_model(device)
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    eps = np.array([0.0, -0.0, 1e-7, -1e-7, 1e-5, -3e-5, 3e-4, -1e-3, 2e-3, -4e-3], dtype=np.float32)
+    rays_o, rays_d = [], []
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            for ea in eps:
+                for eb in eps:
+                    for rep in range(7):
+                        d = np.zeros(3, dtype=np.float32)
+                        d[axis] = sign
+                        d[(axis + 1) % 3] = ea
+                        d[(axis + 2) % 3] = eb
+                        o = rng.uniform(-0.9, 0.9, 3).astype(np.float32)
+                        o[axis] = -sign * 1.7
+                        rays_o.append(o)
+                        rays_d.append(d / np.linalg.norm(d))
+    ro, rd = np.stack(rays_o), np.stack(rays_d).astype(np.float32)
+    N = ro.shape[0]
+    outs, probes = {}, {}
+    stamps = torch.zeros(16, dtype=torch.int64, device=device)
+    try:
+        for flags in (0, 1, 131072, 131072 | 1):
+            lib.ngp_debug_disable_march_queue(flags)
+            h = torch.zeros(N, dtype=torch.int32, device=device)
+            lib.ngp_debug_set_sample_hash(h.data_ptr())
+            stamps.zero_()
+            lib.ngp_debug_set_stamps(stamps.data_ptr())
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                r = model.render(_t(ro, device)[None], _t(rd, device)[None], bg_color=1, perturb=False)
+            torch.cuda.synchronize()
+            lib.ngp_debug_set_stamps(None)
+            outs[flags] = (h.clone(), r["image"].float().clone(), dict(model.last_render_stats))
+            probes[flags] = int(stamps[5])
+    finally:
+        lib.ngp_debug_set_stamps(None)
+        lib.ngp_debug_set_sample_hash(None)
+        lib.ngp_debug_disable_march_queue(0)
+    for flags in (0, 131072, 131072 | 1):
+        assert torch.equal(outs[1][0], outs[flags][0]) and torch.equal(outs[1][1], outs[flags][1]), flags
+        for key in ("samples_marched", "samples_slots", "iterations"):
+            assert outs[1][2][key] == outs[flags][2][key], (flags, key)
+    assert outs[0][2]["samples_marched"] > 5 * N, outs[0][2]                 # the rays cross the scene
+    assert probes[131072] < 0.6 * probes[131072 | 1], probes          # and leave its empty blocks in single steps
+    # against the oracle's march of the same rays (rays whose termination fp16 noise moved excepted, as in the test below)
+    want = Hh.oracle_run_cuda(setup[2], ro, rd, sc.bitfield(), sc.bound, sc.cascade, sc.density_scale)
+    same = outs[0][0].cpu().numpy().view(np.uint32) == want["sample_hash"]
+    assert same.mean() > 0.995, same.mean()
 
 
 def test_launch_cut_short_before_the_network_and_narrow_work_items(device):
