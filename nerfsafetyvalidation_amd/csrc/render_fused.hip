@@ -3448,7 +3448,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         launches += 3;
         // consume every status that has already landed; block only when too far ahead
         while (known < launched) {
-            const bool must_wait = launched - known >= (uint32_t)kLookahead;
+            static const uint32_t lookahead = getenv("NGP_LOOKAHEAD") ? (uint32_t)atoi(getenv("NGP_LOOKAHEAD")) : (uint32_t)kLookahead;   // (A/B timing)
+            const bool must_wait = launched - known >= lookahead;
             volatile unsigned long long* slot = ctx->status + known % kRing;
             const uint32_t want_seq = ctx->seq_base + known + 1;
             unsigned long long w = *slot;
@@ -3456,7 +3457,10 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
                 if (!must_wait) break;
                 uint32_t spins = 0;
                 while ((uint32_t)((w = *slot) >> 32) != want_seq) {
-                    if ((++spins & 0xFFFu) == 0) {   // every few thousand polls make sure the stream is still alive
+                    // every 2^20 polls (tens of milliseconds: far longer than any launch) make sure the stream is still alive.  Rarely,
+                    // because the query is not free on the device side: the runtime answers it with a marker packet in the queue, and the
+                    // kernels behind it start ~6 us late -- at every 4096 polls that was one gap per launch (kernel timeline, round 3)
+                    if ((++spins & 0xFFFFFu) == 0) {
                         const hipError_t q = hipStreamQuery(s);
                         if (q != hipSuccess && q != hipErrorNotReady) {
                             set_error("render_rays: %s", hipGetErrorString(q));
