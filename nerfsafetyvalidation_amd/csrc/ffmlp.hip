@@ -567,6 +567,23 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_chain(const _Float16* __restr
 // partials in a fixed order.  The activation gradients are rounded to fp16 exactly where the two-kernel form rounds them.
 // NL = hidden matrices (num_layers - 1).
 constexpr uint32_t kFusedTPW = 2, kFusedRows = 4 * kFusedTPW * 16;
+// The fused kernel's weight images are read both ways: transposed (dgrad, ds_read_b64_tr_b16: conflict-free with 40 dwords per row) and
+// row-wise (RECOMP's A fragments, ds_read_b64: rows c and c + 8 of a 32-lane half then share their banks modulo 64 -- a 2-way conflict on
+// every read).  Rows with bit 3 set keep the two 8-byte halves of each 16-byte chunk swapped: the row reads of c and c + 8 then fall on
+// different banks, and a transposing read -- whose four rows share that bit -- reads the same chunks of its rows, permuted.
+__device__ __forceinline__ void stage_matrix_sw(_Float16* dst, const _Float16* __restrict__ src, uint32_t rows, uint32_t cols, uint32_t stride) {
+    const uint32_t cpr = cols >> 3, n = rows * cpr;
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const uint32_t r = e / cpr, cc = e - r * cpr;
+        uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)r * cols + cc * 8);
+        if (r & 8u) v = make_uint4(v.z, v.w, v.x, v.y);
+        *reinterpret_cast<uint4*>(dst + r * stride + cc * 8) = v;
+    }
+}
+__device__ __forceinline__ half8v lds_a_frag_sw(const _Float16* mat, uint32_t stride, uint32_t ob, uint32_t kb, uint32_t c, uint32_t q) {
+    const _Float16* p = mat + (size_t)(ob * 16 + c) * stride + kb * 32 + (q ^ ((c >> 3) & 1u)) * 4;
+    return cat8(*reinterpret_cast<const half4*>(p), *reinterpret_cast<const half4*>(p + 16));
+}
 __device__ __forceinline__ half8v tr_pair(const _Float16* p, uint32_t stride16) {   // two 16-row tiles, k = 0..31
     return cat8(lds_tr_read(p), lds_tr_read(p + stride16));
 }
@@ -584,8 +601,16 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const uint32_t sIn = lds_stride(in_dim), IB = in_dim >> 4;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const uint32_t tr_row = 4 * g + (c >> 2), tr_col = 4 * (c & 3);
-    const uint32_t trl_H = tr_row * SH + tr_col, trl_I = tr_row * sIn + tr_col;
+    const uint32_t tr_row = 4 * g + (c >> 2);
+    const uint32_t tr_col_w = 4 * ((c & 3) ^ (g >> 1));                                   // weight images: see stage_matrix_sw
+    const uint32_t trl_H = tr_row * SH + tr_col_w, trl_I = tr_row * sIn + tr_col_w;
+    // The two shared images (Gt, Xt) are written a row per lane -- sixteen rows of one 8-byte column chunk per ds_write_b64 group, and
+    // with 40 dwords per row (the stride that keeps the transposing reads conflict-free: banks modulo 64) rows c, c + 4, c + 8, c + 12
+    // fall on the same banks modulo 32: every store was a 4-way conflict, 1.0-1.5 G conflict cycles per launch against 0.15-0.23 G LDS
+    // instructions (PMC, round 3).  Chunk p of a 16-column block of row r is therefore kept at chunk p ^ ((r >> 2) & 3): the stores of
+    // a group then cover 32 distinct banks, and a transposing read -- whose four rows share r >> 2 -- still reads the four chunks of
+    // each of its rows, permuted.  gsw / trl_S: the writer's and the reader's column under that permutation.
+    const uint32_t gsw = 4 * (g ^ (c >> 2)), trl_S = tr_row * SH + 4 * ((c & 3) ^ g);
     const _Float16* W_in = weights;
     const _Float16* W_hid = weights + (size_t)HID * in_dim;
     const _Float16* W_out = W_hid + (size_t)NL * HID * HID;
@@ -594,9 +619,9 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
     _Float16* Xt = lds + off_X;
     const size_t BH = (size_t)B * HID;
     const uint32_t n_tiles = B >> 4;
-    stage_matrix(lds, W_out, 16, HID, SH);
-    for (uint32_t m = 0; m < (uint32_t)NL; m++) stage_matrix(lds + off_hid + m * HID * SH, W_hid + (size_t)m * HID * HID, HID, HID, SH);
-    if (grad_inputs || RECOMP) stage_matrix(lds + off_in, W_in, HID, in_dim, sIn);
+    stage_matrix_sw(lds, W_out, 16, HID, SH);
+    for (uint32_t m = 0; m < (uint32_t)NL; m++) stage_matrix_sw(lds + off_hid + m * HID * SH, W_hid + (size_t)m * HID * HID, HID, HID, SH);
+    if (grad_inputs || RECOMP) stage_matrix_sw(lds + off_in, W_in, HID, in_dim, sIn);
     __syncthreads();
     f32x4 aO = (f32x4){0, 0, 0, 0}, aH[NL][HB], aI[HB];
 #pragma unroll
@@ -647,7 +672,7 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
                         const half8v xb = cat8(xin[t][2 * kb], xin[t][2 * kb + 1]);
 #pragma unroll
                         for (int ob = 0; ob < HB; ob++)
-                            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_a_frag(lds + off_in, sIn, ob, kb, c, g), xb, acc[ob], 0, 0, 0);
+                            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_a_frag_sw(lds + off_in, sIn, ob, kb, c, g), xb, acc[ob], 0, 0, 0);
                     }
                 }
 #pragma unroll
@@ -662,7 +687,7 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
                         const half8v hb = cat8(fa[m][t][2 * kb], fa[m][t][2 * kb + 1]);
 #pragma unroll
                         for (int ob = 0; ob < HB; ob++)
-                            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_a_frag(Wl, SH, ob, kb, c, g), hb, acc[ob], 0, 0, 0);
+                            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_a_frag_sw(Wl, SH, ob, kb, c, g), hb, acc[ob], 0, 0, 0);
                     }
 #pragma unroll
                     for (int ob = 0; ob < HB; ob++) fa[m + 1][t][ob] = act_hidden<RELU>(act, acc[ob]);
@@ -674,9 +699,9 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
             half4 (&fl)[TPW][HB] = fa[L - 1];
 #pragma unroll
             for (int t = 0; t < (int)TPW; t++) {
-                st_half4(Gt + lrow[t] + g * 4, valid[t] ? gB[t] : zero4);
+                st_half4(Gt + lrow[t] + gsw, valid[t] ? gB[t] : zero4);
 #pragma unroll
-                for (int ib = 0; ib < HB; ib++) st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? fl[t][ib] : zero4);
+                for (int ib = 0; ib < HB; ib++) st_half4(Xt + lrow[t] + ib * 16 + gsw, valid[t] ? fl[t][ib] : zero4);
             }
 #pragma unroll
             for (int ib = 0; ib < HB; ib++) {
@@ -691,8 +716,8 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
             __syncthreads();
 #pragma unroll
             for (uint32_t ks = 0; ks < kFusedRows / 32; ks++)
-                aO = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_pair(Gt + ks * 32 * SH + trl_H, 16 * SH),
-                                                            tr_pair(Xt + ks * 32 * SH + trl_H + wave * 16, 16 * SH), aO, 0, 0, 0);
+                aO = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_pair(Gt + ks * 32 * SH + trl_S, 16 * SH),
+                                                            tr_pair(Xt + ks * 32 * SH + trl_S + wave * 16, 16 * SH), aO, 0, 0, 0);
             __syncthreads();
         }
         // ---- hidden matrices, last to first: dW_hid[m] = dH_{m+1}^T * fwd[m]; dH_m^T = W_hid[m]^T * dH_{m+1}^T ----
@@ -705,8 +730,8 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
             for (int t = 0; t < (int)TPW; t++)
 #pragma unroll
                 for (int ib = 0; ib < HB; ib++) {
-                    st_half4(Gt + lrow[t] + ib * 16 + g * 4, valid[t] ? dh[t][ib] : zero4);
-                    st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? fm[t][ib] : zero4);
+                    st_half4(Gt + lrow[t] + ib * 16 + gsw, valid[t] ? dh[t][ib] : zero4);
+                    st_half4(Xt + lrow[t] + ib * 16 + gsw, valid[t] ? fm[t][ib] : zero4);
                 }
             half4 dn[TPW][HB];
 #pragma unroll
@@ -729,10 +754,10 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
             __syncthreads();
 #pragma unroll
             for (uint32_t ks = 0; ks < kFusedRows / 32; ks++) {
-                const half8v a = tr_pair(Gt + ks * 32 * SH + trl_H + wave * 16, 16 * SH);
+                const half8v a = tr_pair(Gt + ks * 32 * SH + trl_S + wave * 16, 16 * SH);
 #pragma unroll
                 for (int ib = 0; ib < HB; ib++)
-                    aH[m][ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, tr_pair(Xt + ks * 32 * SH + trl_H + ib * 16, 16 * SH), aH[m][ib], 0, 0, 0);
+                    aH[m][ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, tr_pair(Xt + ks * 32 * SH + trl_S + ib * 16, 16 * SH), aH[m][ib], 0, 0, 0);
             }
             __syncthreads();
 #pragma unroll
@@ -745,17 +770,17 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
         for (int t = 0; t < (int)TPW; t++)
 #pragma unroll
             for (int ib = 0; ib < HB; ib++) {
-                st_half4(Gt + lrow[t] + ib * 16 + g * 4, valid[t] ? dh[t][ib] : zero4);
-                if (ib < (int)IB) st_half4(Xt + lrow[t] + ib * 16 + g * 4, valid[t] ? xin[t][ib] : zero4);
+                st_half4(Gt + lrow[t] + ib * 16 + gsw, valid[t] ? dh[t][ib] : zero4);
+                if (ib < (int)IB) st_half4(Xt + lrow[t] + ib * 16 + gsw, valid[t] ? xin[t][ib] : zero4);
             }
         __syncthreads();
 #pragma unroll
         for (uint32_t ks = 0; ks < kFusedRows / 32; ks++) {
-            const half8v a = tr_pair(Gt + ks * 32 * SH + trl_H + wave * 16, 16 * SH);
+            const half8v a = tr_pair(Gt + ks * 32 * SH + trl_S + wave * 16, 16 * SH);
 #pragma unroll
             for (int ib = 0; ib < HB; ib++)
                 if (ib < (int)IB)
-                    aI[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, tr_pair(Xt + ks * 32 * SH + trl_H + ib * 16, 16 * SH), aI[ib], 0, 0, 0);
+                    aI[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, tr_pair(Xt + ks * 32 * SH + trl_S + ib * 16, 16 * SH), aI[ib], 0, 0, 0);
         }
         // ---- dL/dinput = dH_0 * W_in ----
         if (grad_inputs) {
