@@ -568,20 +568,20 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_chain(const _Float16* __restr
 // NL = hidden matrices (num_layers - 1).
 constexpr uint32_t kFusedTPW = 2, kFusedRows = 4 * kFusedTPW * 16;
 // The fused kernel's weight images are read both ways: transposed (dgrad, ds_read_b64_tr_b16: conflict-free with 40 dwords per row) and
-// row-wise (RECOMP's A fragments, ds_read_b64: rows c and c + 8 of a 32-lane half then share their banks modulo 64 -- a 2-way conflict on
-// every read).  Rows with bit 3 set keep the two 8-byte halves of each 16-byte chunk swapped: the row reads of c and c + 8 then fall on
-// different banks, and a transposing read -- whose four rows share that bit -- reads the same chunks of its rows, permuted.
+// row-wise (RECOMP's A fragments: the compiler pairs the two 8-byte reads into ds_read2_b64 -- 16-lane groups, banks modulo 32, where
+// rows c, c + 4, c + 8, c + 12 share their banks: a 4-way conflict on every read).  Same permutation as the shared images below: the
+// 8-byte chunk p of a 16-column block of row r is kept at p ^ ((r >> 2) & 3); a transposing read's four rows share r >> 2.
 __device__ __forceinline__ void stage_matrix_sw(_Float16* dst, const _Float16* __restrict__ src, uint32_t rows, uint32_t cols, uint32_t stride) {
     const uint32_t cpr = cols >> 3, n = rows * cpr;
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        const uint32_t r = e / cpr, cc = e - r * cpr;
-        uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)r * cols + cc * 8);
-        if (r & 8u) v = make_uint4(v.z, v.w, v.x, v.y);
-        *reinterpret_cast<uint4*>(dst + r * stride + cc * 8) = v;
+        const uint32_t r = e / cpr, cc = e - r * cpr, sg = (r >> 2) & 3u;
+        uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)r * cols + cc * 8);       // chunks 2 (cc & 1), 2 (cc & 1) + 1 of block cc >> 1
+        if (sg & 1u) v = make_uint4(v.z, v.w, v.x, v.y);
+        *reinterpret_cast<uint4*>(dst + r * stride + (cc ^ (sg >> 1)) * 8) = v;
     }
 }
 __device__ __forceinline__ half8v lds_a_frag_sw(const _Float16* mat, uint32_t stride, uint32_t ob, uint32_t kb, uint32_t c, uint32_t q) {
-    const _Float16* p = mat + (size_t)(ob * 16 + c) * stride + kb * 32 + (q ^ ((c >> 3) & 1u)) * 4;
+    const _Float16* p = mat + (size_t)(ob * 16 + c) * stride + kb * 32 + (q ^ ((c >> 2) & 3u)) * 4;
     return cat8(*reinterpret_cast<const half4*>(p), *reinterpret_cast<const half4*>(p + 16));
 }
 __device__ __forceinline__ half8v tr_pair(const _Float16* p, uint32_t stride16) {   // two 16-row tiles, k = 0..31
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const 
     const uint32_t sIn = lds_stride(in_dim), IB = in_dim >> 4;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const uint32_t tr_row = 4 * g + (c >> 2);
-    const uint32_t tr_col_w = 4 * ((c & 3) ^ (g >> 1));                                   // weight images: see stage_matrix_sw
+    const uint32_t tr_col_w = 4 * ((c & 3) ^ g);                                          // every image: chunk p of row r at p ^ ((r >> 2) & 3)
     const uint32_t trl_H = tr_row * SH + tr_col_w, trl_I = tr_row * sIn + tr_col_w;
     // The two shared images (Gt, Xt) are written a row per lane -- sixteen rows of one 8-byte column chunk per ds_write_b64 group, and
     // with 40 dwords per row (the stride that keeps the transposing reads conflict-free: banks modulo 64) rows c, c + 4, c + 8, c + 12
