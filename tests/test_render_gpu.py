@@ -407,7 +407,7 @@ def test_launch_cut_short_before_the_network_and_narrow_work_items(device):
     N = ro.shape[0]
     outs = {}
     try:
-        for flags in (0, 16384, 32768, 16384 | 32768 | 256):
+        for flags in (0, 16384, 32768, 131072, 16384 | 32768 | 256):     # (131072: no launch marches one wave per ray -- the last ones of this frame do)
             lib.ngp_debug_disable_march_queue(flags)
             hashes = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(hashes.data_ptr())
@@ -423,7 +423,7 @@ def test_launch_cut_short_before_the_network_and_narrow_work_items(device):
     assert ref[3]["replayed"] == 0
     assert outs[16384][3]["replayed"] >= 1                           # as planned: the first launch fails its verification
     assert outs[0][3]["replayed"] < outs[16384][3]["replayed"]      # cut short instead
-    for flags in (0, 16384, 32768):
+    for flags in (0, 16384, 32768, 131072):
         got = outs[flags]
         # (depth is 0 / 0 = NaN on the rays that miss the box, renderer.py:381)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1].nan_to_num(nan=-7.0), ref[1].nan_to_num(nan=-7.0)) and torch.equal(got[2], ref[2]), flags
