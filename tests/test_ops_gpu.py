@@ -126,10 +126,11 @@ def test_march_rays_step_budget_bit_exact(device, max_steps):
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("perturb,edge", [(False, 48), (True, 48), (True, 24), (False, 136)])
+@pytest.mark.parametrize("perturb,edge", [(False, 48), (True, 48), (True, 24), (False, 136), (True, 47)])
 def test_march_rays_train_bit_exact(device, perturb, edge):
-    """(edge 48: 2304 rays -- derived occupancy copies + the count pass's (t, dt) trace replayed by the write pass; 24: 576 rays --
-    the plain two-pass form; 136: 18496 rays -- derived copies, both passes march)"""
+    """(edge 48: 2304 rays -- derived occupancy copies, one wave per ray on the step lattice, the count pass's (t, dt) trace replayed by
+    the write pass; 47: 2209 rays, a ray count that fills neither the last workgroup nor the last 256-ray block of the slot scan; 24:
+    576 rays -- the plain two-pass form; 136: 18496 rays -- derived copies, both passes march a lane per ray)"""
     from nerfsafetyvalidation_amd import raymarching
     sc = _scene(H=edge, W=edge)
     rays_o, rays_d = _rays(sc, view=33)
