@@ -102,3 +102,13 @@ def test_get_rays_autocast_guard_is_per_call():
     assert not hasattr(U.get_rays, "__wrapped__"), "get_rays must not be wrapped by a shared autocast decorator instance"
     src = inspect.getsource(U.get_rays)
     assert 'with torch.autocast("cuda", enabled=False)' in src
+
+
+def test_graphed_step_needs_a_device():
+    """nerfsafetyvalidation_amd/graphs.py: no silent eager fallback -- without a GPU there is nothing to capture"""
+    import torch
+    from nerfsafetyvalidation_amd.graphs import GraphedStep
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_graphs_gpu.py")
+    with pytest.raises(RuntimeError):
+        GraphedStep(lambda: None, ())
