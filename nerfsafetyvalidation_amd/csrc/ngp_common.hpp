@@ -346,7 +346,13 @@ struct Dda {
         return true;
     }
 
-    __device__ __forceinline__ bool probe_lin(float& t, float& x, float& y, float& z, float& dt, const uint32_t* coarse) const {
+    // `occupied_until` (optional): when the probe finds its cell occupied, the time up to which every later position of the ray is
+    // CERTAIN to be located in this same cell by the reference's arithmetic -- the cell's exit time less the rounding allowance of
+    // jump_block (all three axes counted: a generous bound).  A position before it moves towards each exit face and stays eight ulps of a
+    // coordinate short of it, so its cell indices are these; the cascade level changes only at cube surfaces, which are cell faces.
+    // The march can take its samples up to there without probing (the samples' own arithmetic -- t, dt, t += dt -- is untouched).
+    __device__ __forceinline__ bool probe_lin(float& t, float& x, float& y, float& z, float& dt, const uint32_t* coarse,
+                                              float* occupied_until = nullptr) const {
         float mip_bound;
         int level, nx, ny, nz;
         locate_lin(t, x, y, z, dt, level, mip_bound, nx, ny, nz);
@@ -355,6 +361,15 @@ struct Dda {
         if ((coarse[ci >> 5] >> (ci & 31u)) & 1u) {
             const uint32_t fi = ((uint32_t)level << (3 * logH)) + (((uint32_t)nz << (2 * logH)) | ((uint32_t)ny << logH) | (uint32_t)nx);
             occ = ((grid_lin[fi >> 5] >> (fi & 31u)) & 1u) != 0;
+            if (occ && occupied_until) {
+                const float tx = fmaf(fmaf((float)(nx + sx), two_rH, -1.0f), mip_bound, -x) * rdx;
+                const float ty = fmaf(fmaf((float)(ny + sy), two_rH, -1.0f), mip_bound, -y) * rdy;
+                const float tz = fmaf(fmaf((float)(nz + sz), two_rH, -1.0f), mip_bound, -z) * rdz;
+                const float tt = t + fminf(tx, fminf(ty, tz));
+                const float g = fmaf(tt, 9.5367431640625e-7f, (fabsf(rdx) + fabsf(rdy) + fabsf(rdz)) * jump_guard);
+                const float until = tt - g;
+                *occupied_until = until > t ? until : t;          // (NaN / infinite allowances: nothing is certain)
+            }
         } else if (const_dt && block_jump && jump_block(t, x, y, z, level, mip_bound, nx, ny, nz)) {
             return false;
         }

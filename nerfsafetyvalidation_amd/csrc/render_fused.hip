@@ -2130,6 +2130,7 @@ struct RenderArgs {
     uint32_t n_rays;                  // N: the reference's n_step = clamp(N // n_alive, 1, 8)
     uint32_t pre_verdict;             // k_march_ahead counts the rays whose march runs out per iteration (truncate_launch); 0: diagnostics
     uint32_t wave_march_max;          // launches of at most this many rays march one WAVE per ray (march_ahead_wave); 0: never
+    uint32_t cell_runs;               // k_march_ahead: the samples that follow a probe's in the same occupied cell are taken without probing
 };
 
 // Work items of k_render_iter: W consecutive entries of the alive list, one wave each.  64 while the list fills the chip's wave slots
@@ -2321,21 +2322,26 @@ __global__ void __launch_bounds__(256) k_march_ahead(RenderArgs ra, float bound)
     float2* out = ra.march_samples + ((size_t)(entry >> 6) * n_step) * 64 + (entry & 63u);
     float x, y, z, dt;
     uint32_t probes = 0, probes_coarse_empty = 0, probes_fine_empty = 0;   // diagnostics (ra.stamps): probes of this lane
+    const bool run_cells = LIN && dda.const_dt && ra.cell_runs != 0;
+    float occ_until = 0.0f;              // see Dda::probe_lin: positions before it lie in the occupied cell of the last probe
     while (t_march < far && emitted < n_step) {
         probes++;
         const bool diag_ce = LIN && ra.stamps && dda.coarse_empty_at_lin(t_march, coarse);
         const uint32_t emitted_before = emitted;
-        if (LIN ? dda.probe_lin(t_march, x, y, z, dt, coarse) : dda.probe(t_march, x, y, z, dt, coarse)) {
-            out[(size_t)emitted * 64] = make_float2(t_march, dt);
-            t_march += dt;
-            const float d1 = t_march - last_m;   // deltas[1] of this sample (:791-793)
-            last_m = t_march;
-            geo_tc += d1;
-            emitted++;
-            if (spec && emitted % spec == 0) {   // iteration boundary inside the launch: march_rays starts again from rays_t with last_t = t
-                t_march = geo_tc;
-                last_m = geo_tc;
-            }
+        if (LIN ? dda.probe_lin(t_march, x, y, z, dt, coarse, run_cells ? &occ_until : nullptr) : dda.probe(t_march, x, y, z, dt, coarse)) {
+            // the sample of the probe, then the samples that follow in the same cell: no probe needed to know they are samples
+            do {
+                out[(size_t)emitted * 64] = make_float2(t_march, dt);
+                t_march += dt;
+                const float d1 = t_march - last_m;   // deltas[1] of this sample (:791-793)
+                last_m = t_march;
+                geo_tc += d1;
+                emitted++;
+                if (spec && emitted % spec == 0) {   // iteration boundary inside the launch: march_rays starts again from rays_t with last_t = t
+                    t_march = geo_tc;
+                    last_m = geo_tc;
+                }
+            } while (run_cells && t_march < occ_until && t_march < far && emitted < n_step);
         }
         if (ra.stamps && emitted == emitted_before) { if (diag_ce) probes_coarse_empty++; else probes_fine_empty++; }
     }
@@ -3078,6 +3084,7 @@ struct DebugState {
     bool narrow_items_off() const { return (flags & 32768) != 0; }
     bool prefix_replay_off() const { return (flags & 65536) != 0; }
     bool wave_march_off() const { return (flags & 131072) != 0; }
+    bool cell_runs_off() const { return (flags & 262144) != 0; }
     uint32_t spec_safety_x2() const { return ((uint32_t)flags >> 9) & 15u; }   // 0: kSpecSafetyX2
     uint32_t shrink() const { return ((uint32_t)flags >> 4) & 15u; }
 };
@@ -3339,6 +3346,8 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
         ra.wave_slots = dbg.narrow_items_off() ? 0u : (env ? (uint32_t)atoi(env) : (uint32_t)ctx->num_cu * 16u);
         static const bool no_pre = getenv("NGP_NO_PRE_VERDICT") != nullptr;   // diagnostics: every multi-iteration launch runs as planned
         ra.pre_verdict = (no_pre || dbg.pre_verdict_off()) ? 0u : 1u;
+        static const bool no_runs = getenv("NGP_NO_CELL_RUNS") != nullptr;   // diagnostics (A/B timing): a probe per sample
+        ra.cell_runs = (no_runs || dbg.cell_runs_off()) ? 0u : 1u;
         static const char* wm = getenv("NGP_WAVE_MARCH_MAX");    // diagnostics (A/B timing): 0 = a lane per ray always
         ra.wave_march_max = (dbg.wave_march_off() || dt_gamma != 0.0f) ? 0u : (wm ? (uint32_t)atoi(wm) : (uint32_t)ctx->num_cu * 64u);
     }

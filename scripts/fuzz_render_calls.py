@@ -36,7 +36,7 @@ for i in range(n_calls):
         a = model.render(ro, rd, **kw); sa = dict(model.last_render_stats)
         a2 = model.render(ro, rd, **kw)
         # the same call with one of the renderer's shortcuts switched off (or without the last-iteration tensors): identical bits
-        flags = int(rng.choice([1, 2, 4, 6, 8, 10, 256, 8192, 16384, 32768, 65536, 16384 | 32768 | 65536, 131072, 131072 | 1, 0]))   # (bits 14-16: round 3's launch cut, narrow items, prefix replay; 17: a lane per ray in the march)
+        flags = int(rng.choice([1, 2, 4, 6, 8, 10, 256, 8192, 16384, 32768, 65536, 16384 | 32768 | 65536, 131072, 131072 | 1, 131072 | 262144, 262144, 0]))   # (bits 14-16: round 3's launch cut, narrow items, prefix replay; 17: a lane per ray in the march)
         lib.ngp_debug_disable_march_queue(flags)
         model.return_last_tensors = bool(rng.random() < 0.7)
         try:

@@ -246,7 +246,8 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
         # ... / 4: no slow-ray grouping and 6: no coarse filter either -- the alive list stays in reference order and the last-iteration
         # tensors are written slot-major WHILE launches cover several iterations (the combination of the bound >= 4 scenes)
         # 131072: one lane per ray in every launch (frames this small otherwise march one WAVE per ray, lattice windows of 64 points)
-        for flags in (0, 1, 8, 256, 4, 6, 131072, 131072 | 1, "tiles"):
+        # 131072 | 262144: ... and a probe for every sample (no runs of samples inside one occupied cell)
+        for flags in (0, 1, 8, 256, 4, 6, 131072, 131072 | 1, 131072 | 262144, "tiles"):
             lib.ngp_debug_disable_march_queue(0 if flags == "tiles" else flags)
             h = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(h.data_ptr())
@@ -259,7 +260,7 @@ def test_block_jump_and_linear_layout_keep_the_sample_sequence(setup, device):
         lib.ngp_debug_set_sample_hash(None)
         lib.ngp_debug_disable_march_queue(0)
     assert sc.W % 4 == 0 and N % (4 * sc.W) == 0      # (the hint is only taken for whole rows of tiles)
-    for flags in (1, 8, 256, 4, 6, 131072, 131072 | 1, "tiles"):
+    for flags in (1, 8, 256, 4, 6, 131072, 131072 | 1, 131072 | 262144, "tiles"):
         assert torch.equal(outs[0][0], outs[flags][0]), flags
         assert torch.equal(outs[0][1], outs[flags][1]), flags
         assert torch.equal(outs[0][3], outs[flags][3]) and torch.equal(outs[0][4], outs[flags][4]), flags   # last-iteration tensors
@@ -365,7 +366,7 @@ def test_rays_almost_parallel_to_an_axis_leave_empty_blocks_in_one_step(setup, d
     outs, probes = {}, {}
     stamps = torch.zeros(16, dtype=torch.int64, device=device)
     try:
-        for flags in (0, 1, 131072, 131072 | 1):
+        for flags in (0, 1, 131072, 131072 | 1, 131072 | 262144):
             lib.ngp_debug_disable_march_queue(flags)
             h = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(h.data_ptr())
@@ -381,7 +382,7 @@ def test_rays_almost_parallel_to_an_axis_leave_empty_blocks_in_one_step(setup, d
         lib.ngp_debug_set_stamps(None)
         lib.ngp_debug_set_sample_hash(None)
         lib.ngp_debug_disable_march_queue(0)
-    for flags in (0, 131072, 131072 | 1):
+    for flags in (0, 131072, 131072 | 1, 131072 | 262144):
         assert torch.equal(outs[1][0], outs[flags][0]) and torch.equal(outs[1][1], outs[flags][1]), flags
         for key in ("samples_marched", "samples_slots", "iterations"):
             assert outs[1][2][key] == outs[flags][2][key], (flags, key)
@@ -407,7 +408,7 @@ def test_launch_cut_short_before_the_network_and_narrow_work_items(device):
     N = ro.shape[0]
     outs = {}
     try:
-        for flags in (0, 16384, 32768, 131072, 16384 | 32768 | 256):     # (131072: no launch marches one wave per ray -- the last ones of this frame do)
+        for flags in (0, 16384, 32768, 131072, 262144, 16384 | 32768 | 256):     # (131072: no launch marches one wave per ray -- the last ones of this frame do)
             lib.ngp_debug_disable_march_queue(flags)
             hashes = torch.zeros(N, dtype=torch.int32, device=device)
             lib.ngp_debug_set_sample_hash(hashes.data_ptr())
@@ -423,7 +424,7 @@ def test_launch_cut_short_before_the_network_and_narrow_work_items(device):
     assert ref[3]["replayed"] == 0
     assert outs[16384][3]["replayed"] >= 1                           # as planned: the first launch fails its verification
     assert outs[0][3]["replayed"] < outs[16384][3]["replayed"]      # cut short instead
-    for flags in (0, 16384, 32768, 131072):
+    for flags in (0, 16384, 32768, 131072, 262144):
         got = outs[flags]
         # (depth is 0 / 0 = NaN on the rays that miss the box, renderer.py:381)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1].nan_to_num(nan=-7.0), ref[1].nan_to_num(nan=-7.0)) and torch.equal(got[2], ref[2]), flags
