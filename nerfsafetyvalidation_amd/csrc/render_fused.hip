@@ -34,6 +34,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "ngp_common.hpp"
@@ -3293,6 +3294,13 @@ int ngp_render_ctx_destroy(ngp_render_ctx* c) {
     return NGP_OK;
 }
 
+// Render calls in progress in this process (a scheduling hint only: see the persistent workgroup count in ngp_render_rays)
+static std::atomic<int> g_active_renders{0};
+struct ActiveRender {
+    ActiveRender() { g_active_renders.fetch_add(1, std::memory_order_relaxed); }
+    ~ActiveRender() { g_active_renders.fetch_sub(1, std::memory_order_relaxed); }
+};
+
 int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* rays_o, const float* rays_d, const float* nears,
                     const float* fars, uint32_t N, float dt_gamma, uint32_t max_steps, uint32_t perturb, float* weights_sum, float* depth,
                     float* image, float* last_sigmas, float* last_rgbs, const float* pad_value_host, ngp_render_stats* stats_host, int sync,
@@ -3302,6 +3310,7 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     NGP_REQUIRE((last_sigmas == nullptr) == (last_rgbs == nullptr), "render_rays: last_sigmas and last_rgbs must both be given or both NULL");
     if (stats_host) *stats_host = ngp_render_stats{};
     if (N == 0) return NGP_OK;
+    const ActiveRender active_render;
     NGP_REQUIRE(rays_o && rays_d && nears && fars && weights_sum && depth && image, "render_rays: null pointer");
     NGP_REQUIRE(model && model->density_bitfield, "render_rays: model has no density bitfield");
     NGP_REQUIRE(model->cascade >= 1 && model->cascade <= 8 && model->grid_size >= 2 && model->grid_size <= 1024,
@@ -3428,7 +3437,14 @@ int ngp_render_rays(ngp_render_ctx* ctx, const ngp_model* model, const float* ra
     while (!done) {
         const uint32_t cur = launched & 1;
         const uint32_t chunks = items_bound(ub, ra.wave_slots);     // work items of the launch, at most
-        const uint32_t max_blocks = (uint32_t)ctx->num_cu * blocks_per_cu;   // persistent: resident workgroups pull chunks from a queue
+        // persistent: resident workgroups pull chunks from a queue.  k_render_iter at two workgroups per CU holds every vector register and
+        // 144 KB of the LDS of the CUs it runs on, so nothing of another frame's launches runs beside it; at five eighths of that it
+        // is 5 % slower on its own (its bound is the gather, not the waves in flight) and leaves room for another call's march and
+        // compaction kernels: +2-3 % frames/s with three calls in flight.  Taken when another render call of this process is in progress
+        // (results do not depend on the workgroup count; NGP_ITER_BLOCKS_PCT fixes the percentage for an A/B).
+        static const uint32_t pct_env = getenv("NGP_ITER_BLOCKS_PCT") ? (uint32_t)atoi(getenv("NGP_ITER_BLOCKS_PCT")) : 0u;
+        const uint32_t blocks_pct = pct_env ? pct_env : (g_active_renders.load(std::memory_order_relaxed) > 1 ? 62u : 100u);
+        const uint32_t max_blocks = (uint32_t)ctx->num_cu * blocks_per_cu * blocks_pct / 100u;
         const uint32_t want_blocks = div_up(chunks, kWaves);
         const uint32_t blocks = want_blocks < max_blocks ? want_blocks : max_blocks;
         ra.alive_in = ctx->alive[cur];
