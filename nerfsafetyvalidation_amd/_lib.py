@@ -57,6 +57,10 @@ SIGNATURES = {
     "ngp_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "ngp_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
                        _u32, _vp],
+    "ngp_occupancy_lin_bytes": [_u32, _u32],
+    "ngp_build_occupancy_lin": [_vp, _u32, _u32, _vp, _sz, _vp],
+    "ngp_march_rays_lin": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
+                           _u32, _vp, _vp],
     "ngp_composite_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ngp_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int, _int, _vp, _u32, _vp],
     "ngp_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp, _u32, _int,
@@ -128,7 +132,7 @@ SIGNATURES = {
     "ngp_prof_read": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
 }
 _RESTYPES = {"ngp_render_uniform_backward_lds": _sz, "ngp_cell_tables_bytes": _sz, "ngp_packed_weights_bytes": _sz, "ngp_packed_weights_bwd_bytes": _sz, "ngp_grid_encode_backward_workspace": _sz,
-             "ngp_ffmlp_backward_workspace": _sz, "ngp_ffmlp_backward_buffer_bytes": _sz, "ngp_render_upsample_workspace": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz}
+             "ngp_ffmlp_backward_workspace": _sz, "ngp_ffmlp_backward_buffer_bytes": _sz, "ngp_render_upsample_workspace": _sz, "ngp_density_grid_workspace": _sz, "ngp_last_error": C.c_char_p, "ngp_march_rays_train_workspace": _sz, "ngp_uq_stats_workspace": _sz, "ngp_occupancy_lin_bytes": _sz}
 
 _lib = None
 

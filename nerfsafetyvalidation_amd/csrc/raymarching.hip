@@ -566,13 +566,22 @@ __global__ void __launch_bounds__(kBlock) k_composite_train_bwd(const float* __r
 }
 
 // ------------------------------------------------------------------ march_rays :706-814
+// LIN: the caller holds the derived copies of the occupancy bits (ngp_build_occupancy_lin: x-fastest layout and its 4x4x4-block reduction,
+// as the fused renderer and march_rays_train keep them) -- Dda::probe_lin's cheaper probes, one-step exits from empty blocks, and the
+// samples that follow a probe's in the same occupied cell taken without probing.  Same samples bit for bit (test_march_rays_*).
+template <bool LIN>
 __global__ void __launch_bounds__(kBlock) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
                                                        const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                        const float* __restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
                                                        uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                                                        const float* __restrict__ fars, float* __restrict__ xyzs,
                                                        float* __restrict__ dirs, float* __restrict__ deltas, uint32_t perturb, Pcg32 rng,
-                                                       uint32_t n_rows /* padded rows / n_step, rounded up */, uint32_t M_padded) {
+                                                       uint32_t n_rows /* padded rows / n_step, rounded up */, uint32_t M_padded, TrainLin tl) {
+    __shared__ uint32_t coarse_lds[LIN ? kTrainCoarseBytes / 4 : 1];
+    if (LIN) {
+        for (uint32_t i = threadIdx.x; i < tl.coarse_words; i += kBlock) coarse_lds[i] = tl.coarse[i];
+        __syncthreads();
+    }
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     if (n >= n_rows) return;
     float* pxyz = xyzs + (size_t)n * n_step * 3;
@@ -583,6 +592,7 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(uint32_t n_alive, uint32_
         const int32_t index = rays_alive[n];
         Dda s;
         s.init(rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, dt_gamma, max_steps, C, H);
+        if (LIN) s.init_lin(tl.lin, tl.logH, true);
         float t = rays_t[index];
         const float far = fars[index];
         if (perturb) {
@@ -590,8 +600,20 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(uint32_t n_alive, uint32_
             t += s.dt_min * rng.next_float();
         }
         float last_t = t, x, y, z, dt;
+        const bool run_cells = LIN && s.const_dt;
+        float occ_until = 0.0f;
         while (t < far && step < n_step) {
-            if (s.probe(t, x, y, z, dt)) {
+            bool hit;
+            if (run_cells && t < occ_until) {      // still in the occupied cell of the last probe: a sample (Dda::probe_lin), same position arithmetic
+                x = __builtin_amdgcn_fmed3f(fmaf(t, s.dx, s.ox), -s.bound, s.bound);
+                y = __builtin_amdgcn_fmed3f(fmaf(t, s.dy, s.oy), -s.bound, s.bound);
+                z = __builtin_amdgcn_fmed3f(fmaf(t, s.dz, s.oz), -s.bound, s.bound);
+                dt = s.dt_c;
+                hit = true;
+            } else {
+                hit = LIN ? s.probe_lin(t, x, y, z, dt, coarse_lds, run_cells ? &occ_until : nullptr) : s.probe(t, x, y, z, dt);
+            }
+            if (hit) {
                 pxyz[0] = x; pxyz[1] = y; pxyz[2] = z;
                 pdir[0] = s.dx; pdir[1] = s.dy; pdir[2] = s.dz;
                 t += dt;
@@ -892,11 +914,37 @@ int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float
     return check_launch("composite_rays_train_backward");
 }
 
-int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
-                   const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
-                   const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, uint32_t M_padded,
-                   ngp_stream_t stream) {
-    (void)nears;
+// Derived copies of the occupancy bits for ngp_march_rays_lin: `out` receives the x-fastest re-layout (C * H^3 / 8 bytes) followed, at the
+// next multiple of 256 bytes, by its 1:64 reduction (C * H^3 / 512 bytes).  0 bytes: this grid takes the plain entry point.
+static bool occupancy_lin_ok(uint32_t C, uint32_t H) {
+    if (C < 1 || C > 8 || H < 8 || H > 1024 || (H & (H - 1))) return false;
+    const size_t cells = (size_t)C * H * H * H;
+    return cells % 4096 == 0 && cells / 8 <= kTrainLinBytes && cells / 64 / 8 <= kTrainCoarseBytes;
+}
+size_t ngp_occupancy_lin_bytes(uint32_t C, uint32_t H) {
+    if (!occupancy_lin_ok(C, H)) return 0;
+    const size_t cells = (size_t)C * H * H * H;
+    return (cells / 8 + 255) / 256 * 256 + cells / 512;
+}
+int ngp_build_occupancy_lin(const uint8_t* grid, uint32_t C, uint32_t H, void* out, size_t out_bytes, ngp_stream_t stream) {
+    NGP_REQUIRE(grid && out, "build_occupancy_lin: null pointer");
+    const size_t need = ngp_occupancy_lin_bytes(C, H);
+    NGP_REQUIRE(need && out_bytes >= need, "build_occupancy_lin: C=%u H=%u needs %zu bytes (0 = not supported), %zu given", C, H, need, out_bytes);
+    NGP_REQUIRE(((uintptr_t)grid & 7) == 0 && ((uintptr_t)out & 255) == 0, "build_occupancy_lin: grid must be 8-byte aligned, out 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t cells = (size_t)C * H * H * H;
+    uint32_t logH = 0;
+    while ((1u << logH) < H) logH++;
+    k_build_linear<<<div_up((uint32_t)(cells / 32), 256), 256, 0, s>>>(grid, C, logH, (uint32_t*)out);
+    k_build_coarse_linear<<<div_up((uint32_t)(cells / 64), 256), 256, 0, s>>>((const unsigned long long*)grid, C, logH,
+                                                                             (unsigned long long*)((char*)out + (cells / 8 + 255) / 256 * 256));
+    return check_launch("build_occupancy_lin");
+}
+
+static int march_rays_impl(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                           const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
+                           const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, uint32_t M_padded,
+                           const void* occupancy_lin, ngp_stream_t stream) {
     if (M_padded == 0 || n_step == 0) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, "march_rays: null pointer");
     NGP_REQUIRE((uint64_t)n_alive * n_step <= M_padded, "march_rays: M_padded=%u smaller than n_alive*n_step", M_padded);
@@ -906,9 +954,40 @@ int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
     rng.seed((uint64_t)perturb);  // raymarching.cu:819
     const uint32_t n_rows = div_up(M_padded, n_step);
     ProfScope prof("march_rays", s, (double)n_alive * n_step);
-    k_march_rays<<<div_up(n_rows, kBlock), kBlock, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
-                                                           C, H, grid, fars, xyzs, dirs, deltas, perturb, rng, n_rows, M_padded);
+    TrainLin tl = {};
+    if (occupancy_lin) {
+        NGP_REQUIRE(occupancy_lin_ok(C, H), "march_rays_lin: C=%u H=%u has no derived occupancy copies (ngp_occupancy_lin_bytes is 0)", C, H);
+        const size_t cells = (size_t)C * H * H * H;
+        tl.lin = (const uint32_t*)occupancy_lin;
+        tl.coarse = (const uint32_t*)((const char*)occupancy_lin + (cells / 8 + 255) / 256 * 256);
+        tl.coarse_words = (uint32_t)(cells / 64 / 32);
+        while ((1u << tl.logH) < H) tl.logH++;
+        k_march_rays<true><<<div_up(n_rows, kBlock), kBlock, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
+                                                                     C, H, grid, fars, xyzs, dirs, deltas, perturb, rng, n_rows, M_padded, tl);
+    } else {
+        k_march_rays<false><<<div_up(n_rows, kBlock), kBlock, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
+                                                                      C, H, grid, fars, xyzs, dirs, deltas, perturb, rng, n_rows, M_padded, tl);
+    }
     return check_launch("march_rays");
+}
+
+int ngp_march_rays_lin(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                       const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
+                       const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, uint32_t M_padded,
+                       const void* occupancy_lin, ngp_stream_t stream) {
+    (void)nears;
+    NGP_REQUIRE(occupancy_lin, "march_rays_lin: occupancy_lin is NULL (ngp_build_occupancy_lin fills it; ngp_march_rays needs none)");
+    return march_rays_impl(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
+                           perturb, M_padded, occupancy_lin, stream);
+}
+
+int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                   const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
+                   const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, uint32_t perturb, uint32_t M_padded,
+                   ngp_stream_t stream) {
+    (void)nears;
+    return march_rays_impl(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
+                           perturb, M_padded, nullptr, stream);
 }
 
 int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas, const float* rgbs,

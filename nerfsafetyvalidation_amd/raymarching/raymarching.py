@@ -8,8 +8,13 @@ Deliberate, documented differences that are invisible to callers:
   * march_rays_train allocates ray slots by a prefix sum in ray order (a fixed
     member of the reference's atomicAdd permutation set, SURVEY F7);
   * march_rays' kernel zero-fills unused slots itself, so the wrapper allocates
-    with torch.empty (the reference does torch.zeros + kernel, :328-330).
+    with torch.empty (the reference does torch.zeros + kernel, :328-330);
+  * march_rays keeps derived copies of the occupancy bits (0.5 MB for 128^3 x 2),
+    rebuilt when the bitfield tensor's version changes (ngp_march_rays_lin).
 """
+import collections
+import threading
+
 import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
@@ -18,6 +23,8 @@ from .. import _lib
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "composite_rays"]
+
+USE_OCCUPANCY_LIN = True        # march_rays keeps derived copies of the occupancy bits per bitfield version (False: the plain kernel, for A/B)
 
 _fwd32 = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = custom_bwd(device_type="cuda")
@@ -199,6 +206,35 @@ composite_rays_train = _composite_rays_train.apply
 
 
 # ---------------------------------------------------------------- inference
+# Derived copies of the occupancy bits for ngp_march_rays_lin (the reference's loop calls march_rays once per iteration, dozens of times per
+# frame, with the same bitfield): built once per (bitfield storage, version, stream) -- a stream's copy is written and read on that stream
+# only, so no cross-stream ordering is needed -- and dropped least-recently-used.
+_OCC_LIN = collections.OrderedDict()
+_OCC_LIN_LOCK = threading.Lock()
+_OCC_LIN_MAX = 8
+
+
+def _occupancy_lin(density_bitfield, C, H):
+    L = _lib.lib()
+    nbytes = L.ngp_occupancy_lin_bytes(C, H)
+    if not nbytes or not density_bitfield.is_cuda or density_bitfield.data_ptr() % 8 or density_bitfield.dtype != torch.uint8:
+        return None
+    stream = _lib.stream()
+    key = (density_bitfield.data_ptr(), density_bitfield._version, density_bitfield.device, int(stream or 0), C, H)
+    with _OCC_LIN_LOCK:
+        hit = _OCC_LIN.get(key)
+        if hit is not None:
+            _OCC_LIN.move_to_end(key)
+            return hit
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=density_bitfield.device)      # (torch allocations are 512-byte aligned)
+    _lib.check(L.ngp_build_occupancy_lin(_lib.ptr(density_bitfield), C, H, _lib.ptr(buf), nbytes, stream), "build_occupancy_lin")
+    with _OCC_LIN_LOCK:
+        _OCC_LIN[key] = buf
+        while len(_OCC_LIN) > _OCC_LIN_MAX:
+            _OCC_LIN.popitem(last=False)
+    return buf
+
+
 class _march_rays(Function):
     @staticmethod
     @_fwd32
@@ -214,10 +250,17 @@ class _march_rays(Function):
         dirs = torch.empty(M, 3, dtype=dt, device=dev)
         deltas = torch.empty(M, 2, dtype=dt, device=dev)
         L = _lib.lib()
-        _lib.check(L.ngp_march_rays(n_alive, n_step, _lib.ptr(rays_alive), _lib.ptr(rays_t), _lib.ptr(rays_o),
-                                    _lib.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _lib.ptr(density_bitfield),
-                                    _lib.ptr(near), _lib.ptr(far), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
-                                    int(perturb), M, _lib.stream()), "march_rays")
+        occ = _occupancy_lin(density_bitfield, C, H) if USE_OCCUPANCY_LIN else None
+        if occ is not None:
+            _lib.check(L.ngp_march_rays_lin(n_alive, n_step, _lib.ptr(rays_alive), _lib.ptr(rays_t), _lib.ptr(rays_o),
+                                            _lib.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _lib.ptr(density_bitfield),
+                                            _lib.ptr(near), _lib.ptr(far), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
+                                            int(perturb), M, _lib.ptr(occ), _lib.stream()), "march_rays_lin")
+        else:
+            _lib.check(L.ngp_march_rays(n_alive, n_step, _lib.ptr(rays_alive), _lib.ptr(rays_t), _lib.ptr(rays_o),
+                                        _lib.ptr(rays_d), bound, dt_gamma, max_steps, C, H, _lib.ptr(density_bitfield),
+                                        _lib.ptr(near), _lib.ptr(far), _lib.ptr(xyzs), _lib.ptr(dirs), _lib.ptr(deltas),
+                                        int(perturb), M, _lib.stream()), "march_rays")
         return xyzs, dirs, deltas
 
 

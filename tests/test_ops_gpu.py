@@ -75,9 +75,12 @@ def test_morton_and_packbits_bit_exact(device):
     assert raymarching.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=device)).numel() == 0
 
 
+@pytest.mark.parametrize("lin", [True, False], ids=["derived_occupancy_copies", "plain_kernel"])
 @pytest.mark.parametrize("dt_gamma,perturb", [(0.0, 0), (1.0 / 128, 0), (0.0, 3)])
-def test_march_rays_bit_exact(device, dt_gamma, perturb):
+def test_march_rays_bit_exact(device, dt_gamma, perturb, lin, monkeypatch):
     from nerfsafetyvalidation_amd import raymarching
+    from nerfsafetyvalidation_amd.raymarching import raymarching as rm
+    monkeypatch.setattr(rm, "USE_OCCUPANCY_LIN", lin)
     sc = _scene()
     rays_o, rays_d = _rays(sc)
     N = rays_o.shape[0]
@@ -99,6 +102,47 @@ def test_march_rays_bit_exact(device, dt_gamma, perturb):
     for got, want in zip(g, (xyzs, dirs, deltas)):
         assert got.shape == want.shape
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_march_rays_follows_the_bitfield_it_is_given(device):
+    """march_rays keeps derived copies of the occupancy bits per version of the bitfield tensor (ngp_march_rays_lin): an in-place update of
+    the bitfield (update_extra_state writes it in place) and another bitfield of the same shape must both be seen, and the derived-copy
+    form must equal the plain kernel on each."""
+    from nerfsafetyvalidation_amd import raymarching
+    from nerfsafetyvalidation_amd.raymarching import raymarching as rm
+    sc = _scene()
+    rays_o, rays_d = _rays(sc, view=5)
+    N = rays_o.shape[0]
+    aabb = np.array([-sc.bound] * 3 + [sc.bound] * 3, np.float32)
+    nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+    O.near_far_from_aabb(rays_o, rays_d, aabb, N, 0.2, nears, fars)
+    alive = _t(np.arange(N, dtype=np.int32), device)
+    args = lambda bf: (N, 2, alive, _t(nears, device), _t(rays_o, device), _t(rays_d, device), sc.bound, bf, sc.cascade, 128,   # noqa: E731
+                       _t(nears, device), _t(fars, device), 128, False, 0.0, 1024)
+    bf = _t(sc.bitfield(), device)
+
+    def both(bitfield):
+        out = {}
+        for lin in (True, False):
+            rm.USE_OCCUPANCY_LIN = lin
+            out[lin] = [t.clone() for t in raymarching.march_rays(*args(bitfield))]
+        rm.USE_OCCUPANCY_LIN = True
+        for a, b in zip(out[True], out[False]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        return out[True]
+    try:
+        first = both(bf)
+        assert int((first[2][:, 0] > 0).sum()) > 100
+        bf.zero_()                                            # in place: same storage, new version -> no sample anywhere
+        assert int((both(bf)[2][:, 0] > 0).sum()) == 0
+        bf.fill_(255)                                         # every cell occupied: every ray that meets the box takes its two samples
+        full = both(bf)
+        assert int((full[2][:, 0] > 0).sum()) > int((first[2][:, 0] > 0).sum())
+        again = both(_t(sc.bitfield(), device))               # another tensor of the same shape
+        for a, b in zip(again, first):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    finally:
+        rm.USE_OCCUPANCY_LIN = True
 
 
 @pytest.mark.parametrize("max_steps", [16, 48, 100, 4096])
