@@ -14,6 +14,7 @@ Deliberate, documented differences that are invisible to callers:
 """
 import collections
 import threading
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -207,8 +208,9 @@ composite_rays_train = _composite_rays_train.apply
 
 # ---------------------------------------------------------------- inference
 # Derived copies of the occupancy bits for ngp_march_rays_lin (the reference's loop calls march_rays once per iteration, dozens of times per
-# frame, with the same bitfield): built once per (bitfield storage, version, stream) -- a stream's copy is written and read on that stream
-# only, so no cross-stream ordering is needed -- and dropped least-recently-used.
+# frame, with the same bitfield): built once per (bitfield TENSOR OBJECT, its version, stream) and dropped least-recently-used.  The entry
+# holds a weak reference to the tensor: another tensor that happens to get a freed one's address (and version 0) is not mistaken for it.
+# A stream's copy is written and read on that stream only, so no cross-stream ordering is needed.
 _OCC_LIN = collections.OrderedDict()
 _OCC_LIN_LOCK = threading.Lock()
 _OCC_LIN_MAX = 8
@@ -220,16 +222,19 @@ def _occupancy_lin(density_bitfield, C, H):
     if not nbytes or not density_bitfield.is_cuda or density_bitfield.data_ptr() % 8 or density_bitfield.dtype != torch.uint8:
         return None
     stream = _lib.stream()
-    key = (density_bitfield.data_ptr(), density_bitfield._version, density_bitfield.device, int(stream or 0), C, H)
+    key = (id(density_bitfield), int(stream or 0), C, H)
     with _OCC_LIN_LOCK:
         hit = _OCC_LIN.get(key)
         if hit is not None:
-            _OCC_LIN.move_to_end(key)
-            return hit
+            ref, version, ptr, buf = hit
+            if ref() is density_bitfield and version == density_bitfield._version and ptr == density_bitfield.data_ptr():
+                _OCC_LIN.move_to_end(key)
+                return buf
+            del _OCC_LIN[key]
     buf = torch.empty(nbytes, dtype=torch.uint8, device=density_bitfield.device)      # (torch allocations are 512-byte aligned)
     _lib.check(L.ngp_build_occupancy_lin(_lib.ptr(density_bitfield), C, H, _lib.ptr(buf), nbytes, stream), "build_occupancy_lin")
     with _OCC_LIN_LOCK:
-        _OCC_LIN[key] = buf
+        _OCC_LIN[key] = (weakref.ref(density_bitfield), density_bitfield._version, density_bitfield.data_ptr(), buf)
         while len(_OCC_LIN) > _OCC_LIN_MAX:
             _OCC_LIN.popitem(last=False)
     return buf

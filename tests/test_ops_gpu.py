@@ -141,6 +141,13 @@ def test_march_rays_follows_the_bitfield_it_is_given(device):
         again = both(_t(sc.bitfield(), device))               # another tensor of the same shape
         for a, b in zip(again, first):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        # tensors that come and go at (most likely) the same address, version 0 each, with different contents: none may be served
+        # another's derived copy
+        for fill in (0, 255, 0, 255):
+            tmp = torch.full_like(bf, fill)
+            hits = int((raymarching.march_rays(*args(tmp))[2][:, 0] > 0).sum())
+            assert (hits == 0) == (fill == 0), (fill, hits)
+            del tmp
     finally:
         rm.USE_OCCUPANCY_LIN = True
 
