@@ -307,7 +307,11 @@ static void launch_ffmlp_lds(const uint16_t* in, const uint16_t* w, uint32_t B, 
     ensure_dynamic_lds((const void*)k_ffmlp_forward_lds<HB, R, false, PLANES>, (int)kFfmlpLdsMax);
     const uint32_t n_groups = div_up(B / 16, (uint32_t)R);
     uint32_t blocks = div_up(n_groups, 4);
-    if (blocks > 256 * 2) blocks = 256 * 2;   // two resident workgroups per CU, grid-stride beyond that
+    // resident workgroups per CU, grid-stride beyond that: four of the two-tile form (108-136 registers: four waves per SIMD; the 64-wide
+    // networks -- 0.89 -> 0.77 ms per network on 29.5 M rows against four tiles per wave at two workgroups per CU, which held 196 registers
+    // and left every load and store latency exposed), two of the four-tile forms
+    const uint32_t per_cu = R <= 2 ? 4u : 2u;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     if (act == 0)
         k_ffmlp_forward_lds<HB, R, true, PLANES><<<blocks, 256, lds, s>>>((const _Float16*)in, (const _Float16*)w, B, in_dim, num_layers, act, out_act,
                                                                    (_Float16*)fwd, (_Float16*)out);
@@ -340,14 +344,14 @@ static int ffmlp_run(const uint16_t* inputs, const uint16_t* weights, uint32_t B
         NGP_REQUIRE(hidden_dim == 64 && input_dim % 32 == 0 && ffmlp_lds_halves(input_dim, 64, num_layers) * sizeof(_Float16) <= kFfmlpLdsMax,
                     "%s: the level-major input layout is built for the 64-wide networks with input_dim %% 32 == 0 (got hidden %u, input %u, layers %u)",
                     what, hidden_dim, input_dim, num_layers);
-        launch_ffmlp_lds<4, 4, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s);
+        launch_ffmlp_lds<4, 2, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s);
         return check_launch(what);
     }
     if ((hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128) && input_dim % 32 == 0 &&
         ffmlp_lds_halves(input_dim, hidden_dim, num_layers) * sizeof(_Float16) <= kFfmlpLdsMax) {
         switch (hidden_dim) {
             case 32: launch_ffmlp_lds<2, 4>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
-            case 64: launch_ffmlp_lds<4, 4>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
+            case 64: launch_ffmlp_lds<4, 2>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
             default: launch_ffmlp_lds<8, 2>(inputs, weights, B, input_dim, num_layers, activation, output_activation, fwd, outputs, s); break;
         }
         return check_launch(what);
