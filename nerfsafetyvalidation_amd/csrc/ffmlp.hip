@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_chain(const _Float16* __restr
 // whole persistent loop; each workgroup ends by writing one fp32 partial of every parameter, k_ffmlp_bwd_reduce sums the
 // partials in a fixed order.  The activation gradients are rounded to fp16 exactly where the two-kernel form rounds them.
 // NL = hidden matrices (num_layers - 1).
-constexpr uint32_t kFusedTPW = 2, kFusedRows = 4 * kFusedTPW * 16;
+constexpr uint32_t kFusedTPW = 1, kFusedRows = 4 * kFusedTPW * 16;
 // The fused kernel's weight images are read both ways: transposed (dgrad, ds_read_b64_tr_b16: conflict-free with 40 dwords per row) and
 // row-wise (RECOMP's A fragments: the compiler pairs the two 8-byte reads into ds_read2_b64 -- 16-lane groups, banks modulo 32, where
 // rows c, c + 4, c + 8, c + 12 share their banks: a 4-way conflict on every read).  Same permutation as the shared images below: the
@@ -597,7 +597,7 @@ __device__ __forceinline__ half8v tr_pair(const _Float16* p, uint32_t stride16) 
 // stored.  The forward pass then stores nothing (128 B per row and layer less written there, as many less read here) for 24 / 40 more
 // MFMAs per 32 rows.
 template <int NL, bool PLANES = false, bool RELU = false, bool RECOMP = false>
-__global__ void __launch_bounds__(256, NL <= 2 ? 2 : 1) k_ffmlp_bwd_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
+__global__ void __launch_bounds__(256, NL <= 1 ? 4 : (NL <= 2 ? 3 : 2)) k_ffmlp_bwd_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ inputs,
                                                          const _Float16* __restrict__ weights, const _Float16* __restrict__ fwd, uint32_t B,
                                                          uint32_t in_dim, uint32_t act, _Float16* __restrict__ bwd,
                                                          _Float16* __restrict__ grad_inputs, uint32_t n_groups, float* __restrict__ ws, uint32_t P) {
@@ -831,7 +831,9 @@ static size_t fused_bwd_lds_bytes(uint32_t in_dim, uint32_t NL) {
 }
 static uint32_t fused_bwd_blocks(uint32_t B, uint32_t in_dim, uint32_t NL) {
     const uint32_t n_groups = div_up(B / 16, 4 * kFusedTPW);
-    const uint32_t per_cu = fused_bwd_lds_bytes(in_dim, NL) <= 80 * 1024 ? 2 : 1;
+    const uint32_t fit = (uint32_t)((160 * 1024) / fused_bwd_lds_bytes(in_dim, NL));
+    const uint32_t most = NL <= 1 ? 4u : (NL <= 2 ? 3u : 2u);      // (the kernel's __launch_bounds__)
+    const uint32_t per_cu = fit > most ? most : (fit < 1 ? 1 : fit);
     return n_groups < 256 * per_cu ? n_groups : 256 * per_cu;
 }
 static bool fused_bwd_applies(uint32_t in_dim, uint32_t hidden_dim, uint32_t num_layers) {
