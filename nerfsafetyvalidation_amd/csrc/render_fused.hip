@@ -3177,6 +3177,12 @@ static int fill_net(const ngp_model* m, const DebugState& dbg, const _Float16* p
 }
 
 static size_t weights_bytes(const NetArgs& na) { return net_w_bytes(na); }
+// Workgroups of a grid-strided launch: as many as are RESIDENT at once -- four 256-thread workgroups per CU, or what the LDS holds (the
+// fp32 weights take 40 KB per workgroup: three).  With more, the surplus of every CU runs as a second round at a fraction of the occupancy.
+static uint32_t resident_blocks(size_t lds) {
+    const uint32_t fit = (uint32_t)((160 * 1024) / (lds ? lds : 1));
+    return 256u * (fit > 4 ? 4u : (fit < 1 ? 1u : fit));
+}
 
 // kernel variant of a model: 0 / 1 / 2 = fp16 (AND-reduced indices, generic modulo, per-cell records), 3 / 4 = fp32 (AND, generic),
 // 5 / 6 / 7 = fp16 with the reference's corner rounding
@@ -3602,7 +3608,7 @@ int ngp_debug_fused_features(const ngp_model* model, const float* xyzs, uint32_t
     if (rc) return rc;
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
     uint32_t blocks = div_up(div_up(M, 16), 4);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > resident_blocks(lds)) blocks = resident_blocks(lds);
     if (na.f32()) {   // `features` is float [M, 32] then; one arithmetic only (the operator's)
         if (needs_generic(lv)) k_debug_features32<1><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, (float*)features);
         else k_debug_features32<0><<<blocks, 256, lds, s>>>(na, lv, xyzs, M, (float*)features);
@@ -3674,7 +3680,7 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
     NGP_REQUIRE(lds <= 96 * 1024, "render_uniform: the packed weights need %zu bytes of LDS", lds);
     const int variant = net_variant(na, lv);
     uint32_t blocks = div_up(N, 4);
-    if (blocks > 1024) blocks = 1024;   // 4 workgroups of 4 waves per CU; each wave strides over rays
+    if (blocks > resident_blocks(lds)) blocks = resident_blocks(lds);   // each wave strides over rays
     ProfScope prof("render_uniform", s, (double)N * T);
     // tiles across sixteen neighbouring rays (twice the per-sample rate) once there are enough groups of sixteen to occupy the chip;
     // a pose-estimator batch (1024 scattered pixels, every ray dumped) keeps one ray per wave
@@ -3686,7 +3692,12 @@ int ngp_render_uniform(const ngp_model* model, const float* rays_o, const float*
         uint32_t fw = frame_width;
         if (fw && (fw % 4 != 0 || N % (4 * fw) != 0)) fw = 0;
         uint32_t gb = div_up(div_up(N, 16), 4);
-        if (gb > 1024) gb = 1024;
+        // as many workgroups as are RESIDENT at once (each strides over the groups): four per CU, or what the LDS holds -- the fp32
+        // weights take 40 KB per workgroup, three fit, and with 1024 workgroups the fourth of every CU ran as a second round at a third
+        // of the occupancy (800x800 x 512 samples, fp32: 8.01 -> 7.56 ms; NGP_UNIFORM_BLOCKS fixes the count for an A/B)
+        static const uint32_t gb_env = getenv("NGP_UNIFORM_BLOCKS") ? (uint32_t)atoi(getenv("NGP_UNIFORM_BLOCKS")) : 0u;
+        const uint32_t gb_cap = gb_env ? gb_env : resident_blocks(lds);
+        if (gb > gb_cap) gb = gb_cap;
         NGP_WITH_NET(variant, {
             ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_uniform_x16<NET>), 96 * 1024);
             k_render_uniform_x16<NET><<<gb, 256, lds, s>>>(na, lv, rays_o, rays_d, nears, fars, N, T, lin, weights_sum, depth, image, aggregated_density,
@@ -3883,7 +3894,7 @@ int ngp_network_density(const ngp_model* model, const float* xyzs, uint32_t M, f
     const size_t lds = weights_bytes(na) + sizeof(LevelTab);
     NGP_REQUIRE(lds <= 96 * 1024, "network_density: the packed weights need %zu bytes of LDS", lds);
     uint32_t blocks = div_up(div_up(M, 16), 4);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > resident_blocks(lds)) blocks = resident_blocks(lds);
     ProfScope prof("network_density", s, M);
     NGP_WITH_NET(net_variant(na, lv), {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density<NET>), 96 * 1024);
@@ -3932,7 +3943,7 @@ int ngp_network_forward(const ngp_model* model, const float* xyzs, const float* 
     NGP_REQUIRE(lds <= 96 * 1024, "network_forward: the packed weights need %zu bytes of LDS", lds);
     const uint32_t n_tiles = div_up(M, 16);
     uint32_t blocks = div_up(n_tiles, 4);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > resident_blocks(lds)) blocks = resident_blocks(lds);
     ProfScope prof("network_forward", s, M);
     NGP_WITH_NET(net_variant(na, lv), {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_forward<NET>), 96 * 1024);
