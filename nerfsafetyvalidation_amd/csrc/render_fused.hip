@@ -3918,7 +3918,7 @@ int ngp_network_density_backward(const ngp_model* model, const void* packed_weig
     const size_t lds = weights_bytes(na) + ws + sizeof(LevelTab);
     NGP_REQUIRE(lds <= 160 * 1024, "network_density_backward: LDS budget exceeded (%zu bytes)", lds);
     uint32_t blocks = div_up(div_up(M, 16), 4);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > resident_blocks(lds)) blocks = resident_blocks(lds);
     ProfScope prof("network_density_backward", s, M);
     NGP_WITH_NET(net_variant(na, lv), {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k_network_density_bwd<NET>), 160 * 1024);
