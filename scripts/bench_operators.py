@@ -90,7 +90,12 @@ line("get_rays", "get_rays", N, "rays", 24 * N + 64)
 line("near_far_from_aabb", "near_far_from_aabb", N, "rays", 32 * N)
 line("march_rays_train (two passes + ray-order offsets)", "march_rays_train", M, "samples", 32 * M + (24 + 8 + 12) * N)
 line("grid_encode_forward f16 (training batch: samples in ray order)", "grid_encode_forward", Mp, "points", 588 * Mp)
-line("sh_encode_forward deg 4", "sh_encode_forward", Mp, "points", 76 * Mp)
+# (the training step's SH encoding happens inside ff_sigma_color_input since round 3; the stand-alone operators are timed further down)
+line("ff_sigma_color_input (sigma = exp(h0), colour-net input = [SH4(d) | h1..15 | 0]: one kernel between the FFMLPs)", "ff_sigma_color_input", Mp, "rows",
+     (32 + 12 + 4 + 64) * Mp)
+line("ff_rgb (sigmoid of the colour net's three outputs)", "ff_rgb", Mp, "rows", (32 + 12) * Mp)
+line("ff_rgb_backward", "ff_rgb_backward", Mp, "rows", (12 + 12 + 32) * Mp)
+line("ff_sigma_color_input_backward", "ff_sigma_color_input_backward", Mp, "rows", (64 + 4 + 32 + 32) * Mp)
 line("ffmlp_forward, training (sigma 32-64-64-16 and colour 32-64-64-64-16, averaged)", "ffmlp_forward", Mp, "rows",
      (64 + 32) * Mp, flops_per_call=(14336 + 22528) / 2 * Mp,
      note="bytes: 64 in + 32 out; round 3: the hidden activations are no longer stored (2 or 3 x 128 B per row until then) -- the backward "
@@ -143,6 +148,8 @@ with torch.no_grad():
             dd.grad = None
             enc_sh(dd).backward(gsh)
         torch.cuda.synchronize(); lib.ngp_prof_enable(0)
+    line("sh_encode_forward deg 4 (with the direction derivatives its backward reads)", "sh_encode_forward", Mp, "points", (12 + 64 + 192) * Mp,
+         note="bytes: dirs 12 read, outputs 64 + dy_dx 192 written (the inputs require grad here)")
     line("sh_encode_backward deg 4", "sh_encode_backward", Mp, "points", (64 + 192 + 12 + 12) * Mp,
          note="bytes: grad 64 + dy_dx 192 read, grad_inputs 12 read-modify-write")
     # the sample bookkeeping of `run` and the fused differentiable `run` on the estimator's shape (1024 rays x 512 samples)
