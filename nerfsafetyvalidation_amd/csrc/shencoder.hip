@@ -160,19 +160,30 @@ struct alignas(16) Half8 { _Float16 v[8]; };
 __global__ void __launch_bounds__(kShBlock) k_ff_sigma_color_input(const _Float16* __restrict__ h, const float* __restrict__ dirs, uint32_t B,
                                                                    uint32_t B_pad, ShConst k, float* __restrict__ sigma,
                                                                    _Float16* __restrict__ cin) {
+    // A thread builds its row's 64 bytes; the workgroup writes its rows out through LDS so that consecutive lanes store consecutive 16-byte
+    // chunks (a row per lane means 16-byte stores 64 bytes apart: four partially filled lines per lane and instruction).  Chunk i of
+    // thread t sits at slot 4 t + (i ^ (t & 3)): conflict-free both ways.
+    __shared__ Half8 stage[kShBlock * 4];
     const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
-    if (b >= B_pad) return;
-    Half8* out = reinterpret_cast<Half8*>(cin + (size_t)b * 32);
     Half8 o[4];
-    if (b >= B) {
+    auto flush = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 4; i++) stage[threadIdx.x * 4 + (i ^ (threadIdx.x & 3u))] = o[i];
+        __syncthreads();
+        Half8* blk = reinterpret_cast<Half8*>(cin + (size_t)blockIdx.x * kShBlock * 32);
+        const size_t rows_left = (size_t)B_pad - (size_t)blockIdx.x * kShBlock;          // (whole workgroups reach here: B_pad covers blockIdx.x)
+        const uint32_t n_chunks = (uint32_t)(rows_left < kShBlock ? rows_left : kShBlock) * 4;
 #pragma unroll
-            for (int j = 0; j < 8; j++) o[i].v[j] = (_Float16)0;
-            out[i] = o[i];
+        for (int p = 0; p < 4; p++) {
+            const uint32_t c = p * kShBlock + threadIdx.x, row = c >> 2, i = c & 3u;
+            if (c < n_chunks) blk[c] = stage[row * 4 + (i ^ (row & 3u))];
         }
-        return;
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[i].v[j] = (_Float16)0;
+    if (b < B) {
     const Half8* hr = reinterpret_cast<const Half8*>(h + (size_t)b * 16);
     const Half8 h0 = hr[0], h1 = hr[1];
     sigma[b] = expf((float)h0.v[0]);
@@ -194,15 +205,31 @@ __global__ void __launch_bounds__(kShBlock) k_ff_sigma_color_input(const _Float1
 #pragma unroll
     for (int j = 0; j < 7; j++) o[3].v[j] = h1.v[j + 1];
     o[3].v[7] = (_Float16)0;
+    }
+    flush();          // (every thread of the workgroup: rows past B are zeros, rows past B_pad are not written)
+}
+
+// the same for rows of 32 bytes (two chunks per thread): chunk i of thread t at slot 2 t + (i ^ ((t >> 1) & 1))
+__device__ __forceinline__ void store_rows32(_Float16* __restrict__ dst, const Half8 (&o)[2], uint32_t B_pad, Half8* stage) {
+    const uint32_t t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = o[i];
+    for (int i = 0; i < 2; i++) stage[t * 2 + (i ^ ((t >> 1) & 1u))] = o[i];
+    __syncthreads();
+    Half8* blk = reinterpret_cast<Half8*>(dst + (size_t)blockIdx.x * kShBlock * 16);
+    const size_t rows_left = (size_t)B_pad - (size_t)blockIdx.x * kShBlock;
+    const uint32_t n_chunks = (uint32_t)(rows_left < kShBlock ? rows_left : kShBlock) * 2;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const uint32_t c = p * kShBlock + t, row = c >> 1, i = c & 1u;
+        if (c < n_chunks) blk[c] = stage[row * 2 + (i ^ ((row >> 1) & 1u))];
+    }
 }
 
 __global__ void __launch_bounds__(kShBlock) k_ff_sigma_color_input_bwd(const _Float16* __restrict__ h, const float* __restrict__ g_sigma,
                                                                        const _Float16* __restrict__ g_cin, uint32_t B, uint32_t B_pad,
                                                                        _Float16* __restrict__ g_h) {
+    __shared__ Half8 stage[kShBlock * 2];
     const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
-    if (b >= B_pad) return;
     Half8 o[2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -227,9 +254,7 @@ __global__ void __launch_bounds__(kShBlock) k_ff_sigma_color_input_bwd(const _Fl
             for (int j = 0; j < 7; j++) o[1].v[j + 1] = g3.v[j];
         }
     }
-    Half8* out = reinterpret_cast<Half8*>(g_h + (size_t)b * 16);
-    out[0] = o[0];
-    out[1] = o[1];
+    store_rows32(g_h, o, B_pad, stage);
 }
 
 __global__ void __launch_bounds__(kShBlock) k_ff_rgb(const _Float16* __restrict__ o16, uint32_t B, _Float16* __restrict__ rgb) {
@@ -244,8 +269,8 @@ __global__ void __launch_bounds__(kShBlock) k_ff_rgb(const _Float16* __restrict_
 
 __global__ void __launch_bounds__(kShBlock) k_ff_rgb_bwd(const _Float16* __restrict__ g_rgb, const _Float16* __restrict__ rgb, uint32_t B,
                                                          uint32_t B_pad, _Float16* __restrict__ g_o16) {
+    __shared__ Half8 stage[kShBlock * 2];
     const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
-    if (b >= B_pad) return;
     Half8 o[2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -261,9 +286,7 @@ __global__ void __launch_bounds__(kShBlock) k_ff_rgb_bwd(const _Float16* __restr
             o[0].v[c] = (_Float16)((float)t2 * (float)y);
         }
     }
-    Half8* out = reinterpret_cast<Half8*>(g_o16 + (size_t)b * 16);
-    out[0] = o[0];
-    out[1] = o[1];
+    store_rows32(g_o16, o, B_pad, stage);
 }
 
 }  // namespace ngp
