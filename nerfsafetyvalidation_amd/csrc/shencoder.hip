@@ -73,9 +73,17 @@ template <int DEG, bool GRAD>
 __global__ void __launch_bounds__(kShBlock) k_sh_forward(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B,
                                                          uint32_t D, ShConst k, float* __restrict__ dy_dx) {
     const uint32_t b = blockIdx.x * kShBlock + threadIdx.x;
-    if (b >= B) return;
     constexpr int C2 = DEG * DEG;
-    const float x = inputs[(size_t)b * D], y = inputs[(size_t)b * D + 1], z = inputs[(size_t)b * D + 2];
+    // Degrees up to 4 (the path's: rows of 64 bytes, 192 for the derivatives): a thread's row goes to LDS (stride C2 + 1 words) and the
+    // workgroup writes its rows out as one contiguous run, consecutive lanes to consecutive words -- a row per lane means scattered
+    // 4-byte stores 64 bytes apart (see the kernels between the FFMLPs below).  Same values, same addresses.
+    constexpr bool STAGED = DEG <= 4;
+    constexpr int ROWS = GRAD ? 4 : 1, LS = C2 + 1;
+    __shared__ float stage[STAGED ? kShBlock * LS * ROWS : 1];
+    if (!STAGED && b >= B) return;
+    const bool live = b < B;
+    float x = 0, y = 0, z = 1;
+    if (live) { x = inputs[(size_t)b * D]; y = inputs[(size_t)b * D + 1]; z = inputs[(size_t)b * D + 2]; }
     ShBasis<DEG> s;
     s.build(x, y, z);
     float* out = outputs + (size_t)b * C2;
@@ -87,8 +95,29 @@ __global__ void __launch_bounds__(kShBlock) k_sh_forward(const float* __restrict
             float v, gx, gy, gz;
             sh_term<DEG, GRAD>(s, k, l, m, v, gx, gy, gz);
             const int i = l * l + l + m;
-            out[i] = v;
-            if (GRAD) { dx[i] = gx; dx[C2 + i] = gy; dx[2 * C2 + i] = gz; }
+            if (STAGED) {
+                stage[threadIdx.x * LS + i] = v;
+                if (GRAD) {
+                    stage[(kShBlock + threadIdx.x * 3) * LS + i] = gx;
+                    stage[(kShBlock + threadIdx.x * 3 + 1) * LS + i] = gy;
+                    stage[(kShBlock + threadIdx.x * 3 + 2) * LS + i] = gz;
+                }
+            } else {
+                out[i] = v;
+                if (GRAD) { dx[i] = gx; dx[C2 + i] = gy; dx[2 * C2 + i] = gz; }
+            }
+        }
+    }
+    if (STAGED) {
+        __syncthreads();
+        const uint32_t first = blockIdx.x * kShBlock;
+        const uint32_t rows = B - first < (uint32_t)kShBlock ? B - first : (uint32_t)kShBlock;      // (first < B: the grid covers B)
+        float* o_blk = outputs + (size_t)first * C2;
+        for (uint32_t w = threadIdx.x; w < rows * C2; w += kShBlock) o_blk[w] = stage[(w / C2) * LS + (w % C2)];
+        if (GRAD) {
+            // dy_dx rows are [D = 3][C2] per point: 3 C2 contiguous words per point, staged as three rows of C2
+            float* d_blk = dy_dx + (size_t)first * 3 * C2;
+            for (uint32_t w = threadIdx.x; w < rows * 3 * C2; w += kShBlock) d_blk[w] = stage[(kShBlock + w / C2) * LS + (w % C2)];
         }
     }
 }
