@@ -482,6 +482,15 @@ NGP_API int ngp_uq_stats(const void* c, int c_dtype, const float* d, uint64_t n,
 NGP_API int ngp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
                   float beta2, float eps, uint32_t step, float grad_scale, ngp_stream_t stream);
 
+/* The same step with its scalars on the device: `step_dev` (a float holding the step count: ngp_adam_advance_step adds 1 to it unless
+ * *found_inf_dev != 0 -- call it once per optimiser step, before the tensors' updates), `grad_scale_dev` (the loss scale the gradients carry,
+ * NULL = 1) and `found_inf_dev` (non-zero: skip the update; NULL = never) are what torch.amp.GradScaler hands to an optimiser that declares
+ * _step_supports_amp_scaling.  No value of the step is read by the host: the training loop is not synchronised by its optimiser. */
+NGP_API int ngp_adam_advance_step(float* step_dev, const float* found_inf_dev, ngp_stream_t stream);
+NGP_API int ngp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                      float beta2, float eps, const float* step_dev, const float* grad_scale_dev, const float* found_inf_dev,
+                      ngp_stream_t stream);
+
 /* Diagnostics.  ngp_debug_set_stamps / ngp_debug_set_sample_hash / ngp_debug_disable_march_queue set the PROCESS DEFAULT;
  * ngp_render_ctx_set_debug(ctx, 1, flags, stamps, sample_hash) gives one context its own state (enable = 0: back to the default).
  * A render call snapshots the state that applies to it once, at its start: concurrent calls on other threads / streams are not

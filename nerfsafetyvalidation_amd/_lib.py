@@ -91,6 +91,8 @@ SIGNATURES = {
     "ngp_uq_stats_workspace": [],
     "ngp_uq_stats": [_vp, _int, _vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _sz, _vp],
     "ngp_adam_step": [_vp, _vp, _vp, _vp, C.c_uint64, _f32, _f32, _f32, _f32, _u32, _f32, _vp],
+    "ngp_adam_advance_step": [_vp, _vp, _vp],
+    "ngp_adam_step_dev": [_vp, _vp, _vp, _vp, C.c_uint64, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "ngp_cell_tables_bytes": [C.POINTER(ModelStruct), _u32],
     "ngp_build_cell_tables": [C.POINTER(ModelStruct), _u32, _vp, _vp],
     "ngp_packed_weights_bytes": [],

@@ -189,6 +189,61 @@ __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const 
     }
 }
 
+// The same update with the step count, the loss scale and the overflow flag read ON THE DEVICE (torch.amp.GradScaler hands the last two to
+// an optimiser that sets _step_supports_amp_scaling): nothing of an optimiser step is read back by the host, so a training loop no longer
+// waits for the backward pass before it can enqueue the update and the next step's work.  found_inf != 0: the step is skipped (parameters
+// and moments untouched, the step count not advanced: k_adam_advance), as GradScaler.step skips it.  Bias corrections in double, as the
+// host computes them for k_adam_step.
+__global__ void k_adam_advance(float* __restrict__ step, const float* __restrict__ found_inf) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(found_inf && *found_inf != 0.0f)) *step += 1.0f;
+}
+__global__ void __launch_bounds__(256) k_adam_step_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, uint64_t n, float beta1, float beta2, float eps, float lr,
+                                                       const float* __restrict__ step, const float* __restrict__ grad_scale,
+                                                       const float* __restrict__ found_inf) {
+    if (found_inf && *found_inf != 0.0f) return;
+    __shared__ float s_step_size, s_sqrt_bc2, s_inv;
+    if (threadIdx.x == 0) {
+        const double st = (double)*step;
+        const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
+        s_step_size = (float)((double)lr / bc1);
+        s_sqrt_bc2 = (float)sqrt(bc2);
+        s_inv = grad_scale ? 1.0f / *grad_scale : 1.0f;
+    }
+    __syncthreads();
+    const float step_size = s_step_size, rsqrt_bc2_inv = s_sqrt_bc2, grad_scale_inv = s_inv;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    const bool vec = i0 + 4 <= n && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    float pv[4], gv[4], mv[4], vv[4];
+    const uint32_t cnt = (uint32_t)(n - i0 < 4 ? n - i0 : 4);
+    if (vec) {
+        *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
+        *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i0);
+        *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i0);
+        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i0);
+    } else {
+        for (uint32_t k = 0; k < cnt; k++) { pv[k] = p[i0 + k]; gv[k] = g[i0 + k]; mv[k] = m[i0 + k]; vv[k] = v[i0 + k]; }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k < cnt) {
+            const float gr = gv[k] * grad_scale_inv;
+            mv[k] = mv[k] + (1.0f - beta1) * (gr - mv[k]);
+            vv[k] = beta2 * vv[k] + (1.0f - beta2) * gr * gr;
+            const float denom = sqrtf(vv[k]) / rsqrt_bc2_inv + eps;
+            pv[k] = pv[k] - step_size * (mv[k] / denom);
+        }
+    }
+    if (vec) {
+        *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<float4*>(pv);
+        *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<float4*>(mv);
+        *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<float4*>(vv);
+    } else {
+        for (uint32_t k = 0; k < cnt; k++) { p[i0 + k] = pv[k]; m[i0 + k] = mv[k]; v[i0 + k] = vv[k]; }
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -244,6 +299,23 @@ int ngp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     k_adam_step<<<(uint32_t)((quads + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size,
                                                                                    sqrt_bc2, 1.0f / grad_scale);
     return check_launch("adam_step");
+}
+
+int ngp_adam_advance_step(float* step_dev, const float* found_inf_dev, ngp_stream_t stream) {
+    NGP_REQUIRE(step_dev, "adam_advance_step: null pointer");
+    k_adam_advance<<<1, 64, 0, (hipStream_t)stream>>>(step_dev, found_inf_dev);
+    return check_launch("adam_advance_step");
+}
+
+int ngp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1, float beta2,
+                      float eps, const float* step_dev, const float* grad_scale_dev, const float* found_inf_dev, ngp_stream_t stream) {
+    if (n == 0) return NGP_OK;
+    NGP_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev, "adam_step_dev: null pointer");
+    const uint64_t quads = (n + 3) / 4;
+    ProfScope prof("adam_step", (hipStream_t)stream, (double)n);
+    k_adam_step_dev<<<(uint32_t)((quads + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, lr,
+                                                                                       step_dev, grad_scale_dev, found_inf_dev);
+    return check_launch("adam_step_dev");
 }
 
 int ngp_prof_enable(int on) {

@@ -11,10 +11,50 @@ from . import _lib
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """`device_step=True` (not the default: the reference's optimiser is the host-stepped torch.optim.Adam) keeps the step count on the
+    device and declares `_step_supports_amp_scaling`: `torch.amp.GradScaler.step` then hands over the loss scale and its overflow flag as
+    device tensors instead of reading the flag back (`found_inf.item()`, the one host wait of a training step, nerf/utils.py:674-676), and
+    the kernels unscale, skip on overflow and count the step themselves.  Same arithmetic as the default path; the training loop is no
+    longer synchronised by its optimiser."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, device_step=False):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.device_step = bool(device_step)
+        if self.device_step:
+            self._step_supports_amp_scaling = True
+        self._dev_step = None
+
+    @torch.no_grad()
+    def _step_on_device(self):
+        lib = _lib.lib()
+        found_inf = getattr(self, "found_inf", None)      # set by GradScaler.step around this call (device float tensors), else absent
+        grad_scale = getattr(self, "grad_scale", None)
+        advanced = False
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.is_contiguous():
+                    raise RuntimeError("Adam (HIP): contiguous float32 parameters with dense float32 gradients")
+                st = self.state[p]
+                if self._dev_step is None:                # one count for the optimiser: every tensor steps together
+                    start = float(st["step"]) if "step" in st else 0.0
+                    self._dev_step = torch.full((), start, dtype=torch.float32, device=p.device)
+                if len(st) == 0 or "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = self._dev_step               # (torch's state layout: state_dict() saves it per tensor)
+                if not advanced:
+                    _lib.check(lib.ngp_adam_advance_step(_lib.ptr(self._dev_step), _lib.ptr(found_inf), _lib.stream()), "adam_advance_step")
+                    advanced = True
+                g = p.grad.contiguous()
+                _lib.check(lib.ngp_adam_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(),
+                                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]), _lib.ptr(self._dev_step),
+                                                 _lib.ptr(grad_scale), _lib.ptr(found_inf), _lib.stream()), "adam_step_dev")
+                torch.autograd.graph.increment_version(p)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -22,6 +62,9 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.device_step:
+            self._step_on_device()
+            return loss
         lib = _lib.lib()
         for group in self.param_groups:
             b1, b2 = group["betas"]

@@ -24,7 +24,8 @@ student = sc.build_model(dev, table_seed=1)      # keeps the scene's occupancy g
 student.encoder.reset_parameters()
 student.train()
 student.mean_count = 4096 * 128     # sample capacity per step (the reference tracks a running mean, renderer.py:540-543)
-opt = Adam(student.parameters(), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+# NGP_ADAM_DEVICE_STEP=1: the optimiser's step count / loss scale / overflow flag stay on the device (optim.Adam(device_step=True)): no host wait per step
+opt = Adam(student.parameters(), lr=1e-2, betas=(0.9, 0.99), eps=1e-15, device_step=os.environ.get("NGP_ADAM_DEVICE_STEP") == "1")
 scaler = torch.amp.GradScaler("cuda")
 n_steps, samples = 300, 0
 for step in range(n_steps + 20):

@@ -25,7 +25,7 @@ def run(steps=200, H=64, n_views=8, num_rays=1024, lr=1e-2, device="cuda:0", log
     student.encoder.reset_parameters()          # the reference's initialisation: U(-1e-4, 1e-4)
     student.reset_extra_state()
     student.train()
-    opt = Adam(student.parameters(), lr=lr, betas=(0.9, 0.99), eps=1e-15)
+    opt = Adam(student.parameters(), lr=lr, betas=(0.9, 0.99), eps=1e-15, device_step=os.environ.get("NGP_ADAM_DEVICE_STEP") == "1")
     scaler = torch.amp.GradScaler("cuda")
     losses = []
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -144,3 +144,43 @@ def test_full_frame_training_step_forms_agree(device, monkeypatch):
     assert float(a[1].float().abs().max()) > 0 and float(a[2].float().abs().max()) > 0
     scale = float(b[3].float().abs().max())
     assert scale > 0 and float((a[3].float() - b[3].float()).abs().max()) <= 1e-2 * scale
+
+
+def test_adam_with_device_side_step_follows_the_host_stepped_one(device):
+    """optim.Adam(device_step=True): step count, loss scale and overflow flag stay on the device (GradScaler hands the last two over instead
+    of reading `found_inf` back).  Twelve steps under a GradScaler, one of them with an overflowed gradient: the same steps are taken and
+    skipped as with the host-stepped optimiser, parameters and moments agree (bias corrections are evaluated in double on either side:
+    last-bit differences of the device's pow are allowed for), and the scaler ends at the same scale."""
+    from nerfsafetyvalidation_amd.optim import Adam
+    torch.manual_seed(3)
+    shapes = [(1000, 2), (64, 32), (7,)]
+    init = [torch.randn(s, device=device) for s in shapes]
+    grads = [[torch.randn(s, device=device) * 0.1 for s in shapes] for _ in range(12)]
+
+    def run(device_step):
+        params = [torch.nn.Parameter(t.clone()) for t in init]
+        opt = Adam(params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, device_step=device_step)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=4)
+        versions = [p._version for p in params]
+        scaler.scale(torch.zeros((), device=device))                           # (the scaler creates its device tensors on first use)
+        for it in range(12):
+            for p, g in zip(params, grads[it]):
+                p.grad = g * scaler._scale                                    # gradients of a scaled loss (no host read of the scale)
+            if it == 5:
+                params[1].grad[3, 4] = float("inf")                           # an overflowed step: must be skipped
+            scaler.step(opt)
+            scaler.update()
+        torch.cuda.synchronize()
+        assert all(p._version > v for p, v in zip(params, versions))          # caches keyed on the version see the updates
+        state = [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone(), float(opt.state[p]["step"])) for p in params]
+        return [p.detach().clone() for p in params], state, scaler.get_scale()
+
+    p_host, s_host, scale_host = run(False)
+    p_dev, s_dev, scale_dev = run(True)
+    assert scale_host == scale_dev
+    for a, b, t0 in zip(p_host, p_dev, init):
+        assert not torch.equal(a, t0)                                         # steps were taken
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+    for (m0, v0, st0), (m1, v1, st1) in zip(s_host, s_dev):
+        assert st0 == st1 == 11.0                                             # twelve iterations, one skipped
+        assert torch.allclose(m0, m1, rtol=1e-6, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-6, atol=1e-12)
