@@ -944,6 +944,15 @@ static bool g4_off() {                                   // diagnostics (NGP_GRI
 #define NGP_BIN_NT 1024
 #endif
 constexpr uint32_t kMergeMaxRes = 1024;                   // levels up to this resolution merge across the rays of a workgroup (k_grid_bwd_bin<MERGE>)
+// ... in batches of at least this many points.  The merge pays when the rays of a workgroup are NEIGHBOURS (a whole frame in pixel order:
+// 18.4 -> 14.2 ms for 29.5 M points) and only costs when they are not -- the reference trains on 4096 randomly chosen pixels per step,
+// where nothing is shared across rays: 268 k points 912 -> 1022 steps/s without it, 1 M points 477 -> 493, 4 M 156 -> 161, 10 M 48.1 ->
+// 48.4 (scripts/bench_train_typical.py, NGP_TRAIN_RAYS).  The library cannot see the pixel order; batches this large are frames.
+constexpr uint32_t kMergeMinPoints = 1u << 24;
+static uint32_t merge_min_points() {                     // (NGP_GRID_MERGE_MIN overrides it, read per call: the tests run both variants)
+    const char* e = getenv("NGP_GRID_MERGE_MIN");
+    return e ? (uint32_t)atoll(e) : kMergeMinPoints;
+}
 static uint32_t merge_max_res() {                        // (NGP_GRID_MERGE_RES overrides the threshold: diagnostics)
     static const uint32_t v = getenv("NGP_GRID_MERGE_RES") ? (uint32_t)atoi(getenv("NGP_GRID_MERGE_RES")) : kMergeMaxRes;
     return v;
@@ -1067,7 +1076,7 @@ static void launch_backward(const void* grad, const float* inputs, void* grad_em
         if (!bin_off() && B >= 128u * 1024u)
             for (int pass = 0; pass < 2; pass++) {
                 for (uint32_t l = 0; l < L; l++) {
-                    const bool merge = lv.resolution[l] <= merge_max_res() && !merge_off();
+                    const bool merge = lv.resolution[l] <= merge_max_res() && !merge_off() && B >= merge_min_points();
                     if (merge == (pass == 0) && !((small_mask >> l) & 1u) && lv.offset[l + 1] - lv.offset[l] <= kBinMax * kBinEntries) bl.level[n_bin++] = l;
                 }
                 if (pass == 0) n_merge = n_bin;

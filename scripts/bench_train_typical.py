@@ -23,7 +23,8 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
 student = sc.build_model(dev, table_seed=1)      # keeps the scene's occupancy grid / bitfield
 student.encoder.reset_parameters()
 student.train()
-student.mean_count = 4096 * 128     # sample capacity per step (the reference tracks a running mean, renderer.py:540-543)
+RAYS = int(os.environ.get("NGP_TRAIN_RAYS", "4096"))      # (the reference's 4096; larger batches for A/B of batch-size dependent choices)
+student.mean_count = RAYS * 128     # sample capacity per step (the reference tracks a running mean, renderer.py:540-543)
 # NGP_ADAM_DEVICE_STEP=1: the optimiser's step count / loss scale / overflow flag stay on the device (optim.Adam(device_step=True)): no host wait per step
 opt = Adam(student.parameters(), lr=1e-2, betas=(0.9, 0.99), eps=1e-15, device_step=os.environ.get("NGP_ADAM_DEVICE_STEP") == "1")
 scaler = torch.amp.GradScaler("cuda")
@@ -32,7 +33,7 @@ for step in range(n_steps + 20):
     if step == 20:
         torch.cuda.synchronize(); t0 = time.perf_counter(); samples = 0
     v = step % len(views)
-    rays = get_rays(poses[views[v]:views[v] + 1], sc.intrinsics, H, H, N=4096)
+    rays = get_rays(poses[views[v]:views[v] + 1], sc.intrinsics, H, H, N=RAYS)
     target = images[v][rays["inds"][0]]
     with torch.autocast("cuda", dtype=torch.float16):
         out = student.render(rays["rays_o"], rays["rays_d"], staged=False, bg_color=1, perturb=True, force_all_rays=False)

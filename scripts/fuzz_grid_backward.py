@@ -22,6 +22,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     pct = rng.choice([None, 150, 60, 25, 5])
     if pct is None: os.environ.pop("NGP_GRID_BIN_FILL_PCT", None)
     else: os.environ["NGP_GRID_BIN_FILL_PCT"] = str(pct)
+    if rng.random() < 0.5: os.environ["NGP_GRID_MERGE_MIN"] = "0"          # the merging first pass (default: from 16 M points on)
+    else: os.environ.pop("NGP_GRID_MERGE_MIN", None)
     emb = rng.uniform(-0.5, 0.5, (offsets[-1], C)).astype(np.float32).astype(np.float16)
     o = rng.uniform(0.2, 0.8, (n_rays, 1, 3))
     d = rng.normal(size=(n_rays, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)

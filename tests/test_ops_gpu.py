@@ -442,9 +442,10 @@ def test_ffmlp_level_plane_inputs_equal_row_inputs(device, layers, B):
         wide.forward_padded(planes, planes=True)
 
 
+@pytest.mark.parametrize("merge_min", [0, None], ids=["merging_first_pass", "plain_first_pass_below_16M_points"])
 @pytest.mark.parametrize("dtype,n_rays,T,fill_pct", [(np.float32, 600, 100, None), (np.float16, 600, 100, None), (np.float16, 600, 260, None),
                                                      (np.float16, 160000, 1, None), (np.float16, 600, 260, 60), (np.float16, 160000, 1, 20)])
-def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_pct, monkeypatch):
+def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_pct, merge_min, monkeypatch):
     """Table gradient on a batch in ray order (consecutive points share cells at the coarse levels: the row-level run combining)
     and large enough for the LDS-accumulated levels, against the oracle's scatter; a frozen table gets no gradient and the input
     gradient is unchanged by that.  fill_pct: the regions of the binned scatter sized for that share of the updates only, so that
@@ -452,6 +453,8 @@ def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_p
     from nerfsafetyvalidation_amd.gridencoder import grid_encode
     if fill_pct is not None:
         monkeypatch.setenv("NGP_GRID_BIN_FILL_PCT", str(fill_pct))
+    if merge_min is not None:          # the cross-ray merge of the first pass is taken from 16 M points on: force it for this batch
+        monkeypatch.setenv("NGP_GRID_MERGE_MIN", str(merge_min))
     rng = np.random.default_rng(11)
     D, C, L = 3, 2, 16
     offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=19, desired_resolution=2048)
@@ -511,10 +514,11 @@ def test_grid_encode_backward_ray_ordered_batch(device, dtype, n_rays, T, fill_p
 
 
 @pytest.mark.parametrize("D,gridtype,align", [(2, 0, False), (2, 1, True), (3, 1, False), (3, 0, True)])
-def test_grid_encode_backward_binned_scatter_other_geometries(device, D, gridtype, align):
+def test_grid_encode_backward_binned_scatter_other_geometries(device, D, gridtype, align, monkeypatch):
     """The two-pass scatter (fp16, two features, >= 128 k points) outside the NeRF default: 2-D grids (4 corners per point), the
     tiled grid type and align_corners -- dense and hashed levels, merging and plain first pass -- against the oracle's scatter."""
     from nerfsafetyvalidation_amd.gridencoder import grid_encode
+    monkeypatch.setenv("NGP_GRID_MERGE_MIN", "0")          # (the merging first pass for the coarser levels, as batches of 16 M points take it)
     rng = np.random.default_rng(31 + D)
     C, L = 2, 12
     offsets, pls = Hh.grid_offsets(input_dim=D, num_levels=L, log2_hashmap_size=17, desired_resolution=2048, align_corners=align)
